@@ -1,0 +1,16 @@
+"""CPU oracle for the recursive-LU hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this package
+(see the header of ``rflu_oracle.c``).  The product package never does.
+"""
+from .oracle import (  # noqa: F401
+    build,
+    fill_uniform,
+    generic_lufact,
+    lib,
+    lu,
+    np_uniform,
+    nsplit,
+    residual,
+    unpack_lu,
+)

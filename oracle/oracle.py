@@ -1,0 +1,141 @@
+"""ctypes front-end of ``librflu_oracle.so`` (the C restatement in ``rflu_oracle.c``) plus numpy helpers.
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librflu_oracle.so")
+_lib = None
+
+_i64 = ctypes.c_int64
+_p = ctypes.c_void_p
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (``make -C oracle``).  Returns the path of the shared library."""
+    srcs = [os.path.join(_HERE, f) for f in ("rflu_oracle.c", "rflu_oracle_body.inc", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B" if force else "all"])
+    return _SO
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        for sfx in ("f64", "f32"):
+            getattr(L, f"rfo_lu_{sfx}").restype = _i64
+            getattr(L, f"rfo_lu_{sfx}").argtypes = [_p, _i64, _i64, _i64, _p, ctypes.c_int, _i64, _i64]
+            getattr(L, f"rfo_generic_lufact_{sfx}").restype = _i64
+            getattr(L, f"rfo_generic_lufact_{sfx}").argtypes = [_p, _i64, _i64, _i64, _i64, ctypes.c_int, _p, _i64]
+            getattr(L, f"rfo_nsplit_{sfx}").restype = _i64
+            getattr(L, f"rfo_nsplit_{sfx}").argtypes = [_i64]
+            getattr(L, f"rfo_fill_uniform_{sfx}").restype = None
+            getattr(L, f"rfo_fill_uniform_{sfx}").argtypes = [_p, _i64, _i64, _i64, ctypes.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _sfx(dtype) -> str:
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "f64"
+    if dtype == np.float32:
+        return "f32"
+    raise TypeError(f"oracle handles float64/float32 only, got {dtype}")
+
+
+def nsplit(dtype, n: int) -> int:
+    return int(getattr(lib(), f"rfo_nsplit_{_sfx(dtype)}")(n))
+
+
+def lu(A: np.ndarray, pivot: bool = True, blocksize: int = 0, threshold: int = -1, poison_ipiv=None):
+    """Factor a copy of ``A`` (any layout; copied to column-major).  Returns (factors F-order, ipiv int64 1-based, info).
+
+    Mirrors ``RecursiveFactorization.lu!(A, ipiv, Val(pivot), Val(false); check=false, blocksize, threshold)``
+    (/root/reference/src/lu.jl:97-130); ``info`` uses the positive LAPACK convention.
+    """
+    F = np.array(A, order="F", copy=True)
+    m, n = F.shape
+    ipiv = np.empty(min(m, n), dtype=np.int64)
+    if poison_ipiv is not None:
+        ipiv[:] = poison_ipiv
+    info = getattr(lib(), f"rfo_lu_{_sfx(F.dtype)}")(
+        F.ctypes.data, m, n, max(m, 1), ipiv.ctypes.data, int(bool(pivot)), int(blocksize), int(threshold)
+    )
+    return F, ipiv, int(info)
+
+
+def generic_lufact(A: np.ndarray, pivot: bool = True):
+    """The unblocked panel (/root/reference/src/lu.jl:290-338) on a copy of ``A``."""
+    F = np.array(A, order="F", copy=True)
+    m, n = F.shape
+    mn = min(m, n)
+    ipiv = np.arange(1, mn + 1, dtype=np.int64)
+    info = getattr(lib(), f"rfo_generic_lufact_{_sfx(F.dtype)}")(
+        F.ctypes.data, max(m, 1), m, n, mn, int(bool(pivot)), ipiv.ctypes.data, 0
+    )
+    return F, ipiv, int(info)
+
+
+def fill_uniform(m: int, n: int, seed: int, dtype=np.float64) -> np.ndarray:
+    """Synthetic dense uniform [0,1) input from the C generator (column-major result)."""
+    A = np.empty((m, n), dtype=dtype, order="F")
+    getattr(lib(), f"rfo_fill_uniform_{_sfx(dtype)}")(A.ctypes.data, m, n, max(m, 1), ctypes.c_uint64(seed))
+    return A
+
+
+# ---- numpy mirror of the generator (bit-for-bit equal to rfo_uniform01; checked in tests/test_oracle.py) ----
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def np_uniform(m: int, n: int, seed: int, dtype=np.float64) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(n, dtype=np.uint64)[None, :] * np.uint64(m) + np.arange(m, dtype=np.uint64)[:, None])
+        z = np.uint64(seed) + (ctr + np.uint64(1)) * _GOLD
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return np.asfortranarray(u.astype(dtype))
+
+
+def unpack_lu(F: np.ndarray):
+    """Split packed factors into (L with unit diagonal, U) like LinearAlgebra.LU's .L / .U."""
+    m, n = F.shape
+    k = min(m, n)
+    L = np.tril(F[:, :k], -1) + np.eye(m, k, dtype=F.dtype)
+    U = np.triu(F[:k, :])
+    return L, U
+
+
+def perm_from_ipiv(ipiv: np.ndarray, m: int) -> np.ndarray:
+    """Row permutation p such that (P*A) = A[p, :], from LAPACK-style 1-based sequential interchanges."""
+    p = np.arange(m)
+    for i, ip in enumerate(np.asarray(ipiv)):
+        j = int(ip) - 1
+        if j != i:
+            p[i], p[j] = p[j], p[i]
+    return p
+
+
+def residual(A: np.ndarray, F: np.ndarray, ipiv: np.ndarray):
+    """Returns (max|L*U - A[p,:]|  -- the reference test's norm(.,Inf) on a matrix, test/runtests.jl:20 --,
+    Frobenius ||PA-LU||/||A||), both computed in float64."""
+    A64 = np.asarray(A, dtype=np.float64)
+    L, U = unpack_lu(np.asarray(F, dtype=np.float64))
+    p = perm_from_ipiv(ipiv, A.shape[0])
+    R = L @ U - A64[p, :]
+    nrm = np.linalg.norm(A64)
+    return float(np.max(np.abs(R))) if R.size else 0.0, float(np.linalg.norm(R) / nrm) if nrm > 0 else 0.0

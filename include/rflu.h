@@ -1,0 +1,142 @@
+/*
+ * rflu.h -- C ABI of librflu.so: MI355X-native (gfx950, hand-written HIP) recursive LU with partial pivoting.
+ *
+ * Drop-in boundary for RecursiveFactorization.jl's hot path (citations into /root/reference/):
+ *   lu!(A, ipiv, pivot, thread; check, blocksize, threshold) -> LU(A, ipiv, info)     src/lu.jl:97-130
+ *   recurse!/_recurse!/reckernel! and their four kernels                              src/lu.jl:132-338
+ * The reference is pure Julia and has no FFI today; these entry points are what a `ccall` from its `lu!` method
+ * binds (see INTEGRATION.md for the Julia stub).  Conventions follow what LinearAlgebra.LU / LAPACK getrf expect:
+ *   - matrices are column-major with leading dimension lda >= m; factors overwrite A (strict lower = L with an
+ *     implicit unit diagonal, upper = U);
+ *   - ipiv is int64 (Julia BlasInt on ILP64), 1-based, sequential row interchanges, GLOBAL indices
+ *     (the reference makes them global through `P2 .+= n1`, src/lu.jl:256-260);
+ *   - *info = 0 or the 1-based index of the first exactly-zero pivot, POSITIVE convention; the factorization
+ *     continues past it (src/lu.jl:321-334).  The Julia>=1.11 sign flip for NoPivot (src/lu.jl:25,250,324) and
+ *     `check` -> SingularException (src/lu.jl:128) are applied by the host glue, not here;
+ *   - pivot != 0 is Val(true)/RowMaximum(), pivot == 0 is Val(false)/NoPivot(); with pivot == 0 a non-NULL ipiv is
+ *     filled with the identity 1..min(m,n) (src/lu.jl:111-113), NULL plays the role of NotIPIV (src/lu.jl:27-40).
+ * Return value of every function: 0 on success, non-zero rflu_status on a runtime (HIP / argument) failure --
+ * never a numerical condition.  rflu_last_error() returns a thread-local description of the last failure.
+ * A handle owns one device, one stream and its workspaces; one handle is not thread-safe, distinct handles are.
+ * No function falls back to a CPU implementation.
+ */
+#ifndef RFLU_H
+#define RFLU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rflu_handle_s* rflu_handle_t;
+
+enum rflu_status {
+    RFLU_OK = 0,
+    RFLU_ERR_ARG = 1,      /* bad argument (negative size, lda < m, NULL pointer, unsupported size) */
+    RFLU_ERR_HIP = 2,      /* a HIP runtime call failed */
+    RFLU_ERR_TIMEOUT = 3,  /* the cooperative panel kernel gave up waiting for a peer workgroup */
+    RFLU_ERR_NODEVICE = 4  /* no usable gfx950 device */
+};
+
+/* rflu_last_path values: which implementation served the last getrf call on this handle.  The analogue of the
+ * reference's dispatch-routing tests (test/runtests.jl:86-114,162-192): tests assert the HIP path really ran. */
+enum rflu_path { RFLU_PATH_NONE = 0, RFLU_PATH_HIP_RECURSIVE = 1, RFLU_PATH_HIP_BLOCKED = 2 };
+
+/* kernel classes for the built-in per-kernel timers (rflu_profile_*) */
+enum rflu_kclass {
+    RFLU_K_GEMM = 0,      /* schur_complement!  C -= A*B      (src/lu.jl:265-284), MFMA */
+    RFLU_K_TRSM = 1,      /* ldiv!(UnitLowerTriangular(A11), A12) base blocks (src/lu.jl:235) */
+    RFLU_K_LASWP = 2,     /* apply_permutation! (src/lu.jl:164-188) */
+    RFLU_K_PANEL = 3,     /* _generic_lufact!   (src/lu.jl:290-338) cooperative leaf panel */
+    RFLU_K_TRANSPOSE = 4, /* column-major <-> internal row-major layout change at the boundary */
+    RFLU_K_MISC = 5,      /* pivot bookkeeping, fills */
+    RFLU_K_COUNT = 6
+};
+
+/* ---- lifetime ---- */
+int rflu_create(rflu_handle_t* handle, int device);
+int rflu_destroy(rflu_handle_t handle);
+const char* rflu_last_error(void);
+int rflu_version(void);
+/* Use an existing HIP stream (hipStream_t passed as void*); NULL restores the handle's own stream. */
+int rflu_set_stream(rflu_handle_t handle, void* hip_stream);
+int rflu_synchronize(rflu_handle_t handle);
+int rflu_last_path(rflu_handle_t handle);
+
+/* ---- the boundary: lu!(A, ipiv, pivot; blocksize) on HOST buffers (caller-owned, column-major) ----
+ * Replaces src/lu.jl:114-126 (recursive path + unblocked fallback) for Float64 / Float32.
+ * blocksize: 0 = pure Toledo recursion on the whole matrix (the reference's structure); > 0 = width of the outer
+ * right-looking block column, each factored by the same recursion (`blocksize` re-read as the
+ * GPU panel width, BASELINE config 3 sweeps 64/128/256).  Rounded up to a multiple of 64. */
+int rflu_getrf_f64(rflu_handle_t handle, int64_t m, int64_t n, double* A_host, int64_t lda, int64_t* ipiv_host,
+                   int pivot, int64_t blocksize, int64_t* info);
+int rflu_getrf_f32(rflu_handle_t handle, int64_t m, int64_t n, float* A_host, int64_t lda, int64_t* ipiv_host,
+                   int pivot, int64_t blocksize, int64_t* info);
+
+/* ---- same, DEVICE-resident (A_dev, ipiv_dev are device pointers on the handle's device; info is a host pointer).
+ * Column-major in, column-major out; asynchronous work is completed before return. */
+int rflu_getrf_f64_dev(rflu_handle_t handle, int64_t m, int64_t n, double* A_dev, int64_t lda, int64_t* ipiv_dev,
+                       int pivot, int64_t blocksize, int64_t* info);
+int rflu_getrf_f32_dev(rflu_handle_t handle, int64_t m, int64_t n, float* A_dev, int64_t lda, int64_t* ipiv_dev,
+                       int pivot, int64_t blocksize, int64_t* info);
+
+/* ---- building blocks on the INTERNAL row-major layout: element (i,j) at R[i*ld + j] (device pointers).
+ * These are the four kernels of the path plus the bookkeeping the multi-GPU block-column driver and the parity
+ * tests need.  Pivot rows are GLOBAL 0-based row positions r0.. of the slab; ipiv entries are 1-based rows.
+ * rflu_getrf_rm_*: factor the m x n row-major matrix in place (diagonal at (0,0)); ipiv_dev length min(m,n). */
+int rflu_getrf_rm_f64_dev(rflu_handle_t handle, int64_t m, int64_t n, double* R_dev, int64_t ld, int64_t* ipiv_dev,
+                          int pivot, int64_t blocksize, int64_t* info);
+int rflu_getrf_rm_f32_dev(rflu_handle_t handle, int64_t m, int64_t n, float* R_dev, int64_t ld, int64_t* ipiv_dev,
+                          int pivot, int64_t blocksize, int64_t* info);
+/* Factor the tall panel rows [r0, m) x columns [c0, c0+w) whose diagonal block starts at (r0, c0); writes
+ * ipiv_dev[r0 .. r0+w) (1-based global rows) and the row-interchange bookkeeping used by rflu_laswp_rm_*.
+ * r0 must be a multiple of 64.  *info (host) gets 0 or r0 + k + 1 of the first zero pivot. */
+int rflu_panel_rm_f64_dev(rflu_handle_t handle, int64_t m, int64_t r0, int64_t c0, int64_t w, double* R_dev,
+                          int64_t ld, int64_t* ipiv_dev, int pivot, int64_t* info);
+int rflu_panel_rm_f32_dev(rflu_handle_t handle, int64_t m, int64_t r0, int64_t c0, int64_t w, float* R_dev,
+                          int64_t ld, int64_t* ipiv_dev, int pivot, int64_t* info);
+/* apply_permutation!: apply the interchanges ipiv_dev[k0 .. k1) (row k <-> ipiv[k]-1, in order) to columns
+ * [c0, c0+ncols) of R.  k0 must be a multiple of 64.  m = number of rows of R (bounds for the bookkeeping). */
+int rflu_laswp_rm_f64_dev(rflu_handle_t handle, double* R_dev, int64_t ld, int64_t m, int64_t c0, int64_t ncols,
+                          const int64_t* ipiv_dev, int64_t k0, int64_t k1);
+int rflu_laswp_rm_f32_dev(rflu_handle_t handle, float* R_dev, int64_t ld, int64_t m, int64_t c0, int64_t ncols,
+                          const int64_t* ipiv_dev, int64_t k0, int64_t k1);
+/* B <- L^-1 B, L = unit lower triangle of the n x n block L_dev (row-major, ldl); B is n x nrhs (row-major, ldb). */
+int rflu_trsm_rm_f64_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, const double* L_dev, int64_t ldl,
+                         double* B_dev, int64_t ldb);
+int rflu_trsm_rm_f32_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, const float* L_dev, int64_t ldl, float* B_dev,
+                         int64_t ldb);
+/* C <- C - A*B, all row-major: A is M x K (lda), B is K x N (ldb), C is M x N (ldc). */
+int rflu_gemm_rm_f64_dev(rflu_handle_t handle, int64_t M, int64_t N, int64_t K, const double* A_dev, int64_t lda,
+                         const double* B_dev, int64_t ldb, double* C_dev, int64_t ldc);
+int rflu_gemm_rm_f32_dev(rflu_handle_t handle, int64_t M, int64_t N, int64_t K, const float* A_dev, int64_t lda,
+                         const float* B_dev, int64_t ldb, float* C_dev, int64_t ldc);
+/* Layout change: column-major (m x n, lda) <-> row-major (m x n, ldr). */
+int rflu_cm_to_rm_f64_dev(rflu_handle_t handle, int64_t m, int64_t n, const double* A_cm, int64_t lda, double* R_rm,
+                          int64_t ldr);
+int rflu_rm_to_cm_f64_dev(rflu_handle_t handle, int64_t m, int64_t n, const double* R_rm, int64_t ldr, double* A_cm,
+                          int64_t lda);
+int rflu_cm_to_rm_f32_dev(rflu_handle_t handle, int64_t m, int64_t n, const float* A_cm, int64_t lda, float* R_rm,
+                          int64_t ldr);
+int rflu_rm_to_cm_f32_dev(rflu_handle_t handle, int64_t m, int64_t n, const float* R_rm, int64_t ldr, float* A_cm,
+                          int64_t lda);
+
+/* ---- synthetic input on device (bench / tests; not part of the reference's surface) ----
+ * Fill the m x n sub-block starting at global (i0, j0) of an M_global-row uniform[0,1) matrix:
+ * element (i,j) = u01(seed, (j0+j)*M_global + (i0+i)) -- bit-identical to oracle/rflu_oracle.c:rfo_uniform01.
+ * row_major = 0: A[i + j*ld]; row_major = 1: A[i*ld + j].  diag_add is added to global diagonal entries. */
+int rflu_fill_uniform_f64_dev(rflu_handle_t handle, double* A_dev, int64_t m, int64_t n, int64_t ld, int row_major,
+                              uint64_t seed, int64_t M_global, int64_t i0, int64_t j0, double diag_add);
+int rflu_fill_uniform_f32_dev(rflu_handle_t handle, float* A_dev, int64_t m, int64_t n, int64_t ld, int row_major,
+                              uint64_t seed, int64_t M_global, int64_t i0, int64_t j0, double diag_add);
+/* ---- built-in per-kernel timers (hipEvents on the handle's stream around every launch of a class) ----
+ * enable != 0 starts collecting (and resets); rflu_profile_get returns accumulated milliseconds, launch count and the
+ * algorithmic work (flops for GEMM/TRSM/PANEL, bytes for LASWP/TRANSPOSE) of class k since enabling. */
+int rflu_profile_enable(rflu_handle_t handle, int enable);
+int rflu_profile_get(rflu_handle_t handle, int kclass, double* ms, int64_t* launches, double* work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFLU_H */

@@ -1,0 +1,27 @@
+"""recursivefactorization.jl_amd -- MI355X-native recursive LU behind RecursiveFactorization.jl's ``lu`` / ``lu!`` API.
+
+The product is ``librflu.so`` (hand-written HIP for gfx950, C ABI in ``include/rflu.h``); this package is the thin
+host-side mirror of the reference's interface.  No CPU fallback exists: without the built library and a gfx950 device
+every call raises.
+"""
+from ._ffi import Handle, RfluError, default_handle  # noqa: F401
+from .lu import (  # noqa: F401
+    LU,
+    NOPIVOT_NEGATIVE_INFO,
+    Adjoint,
+    NoPivot,
+    NotIPIV,
+    RowMaximum,
+    SingularException,
+    Transpose,
+    Val,
+    last_path,
+    lu,
+    lu_,
+    normalize_pivot,
+)
+
+__all__ = [
+    "lu", "lu_", "LU", "NotIPIV", "RowMaximum", "NoPivot", "Val", "Adjoint", "Transpose", "SingularException",
+    "normalize_pivot", "last_path", "Handle", "RfluError", "default_handle", "NOPIVOT_NEGATIVE_INFO",
+]

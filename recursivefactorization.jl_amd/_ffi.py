@@ -1,0 +1,136 @@
+"""ctypes binding of librflu.so (include/rflu.h).  The library is the product; this file only marshals pointers.
+
+There is no CPU fallback anywhere in this package: if the shared library is missing or no gfx950 device is visible the
+calls raise ``RfluError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librflu.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_p = ctypes.c_void_p
+c_u64 = ctypes.c_uint64
+c_dbl = ctypes.c_double
+
+
+class RfluError(RuntimeError):
+    """A runtime (HIP / argument) failure reported by librflu -- never a numerical condition."""
+
+
+# every exported symbol of include/rflu.h: name -> (restype, argtypes)
+_TYPED = {
+    "rflu_getrf_{s}": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_int, c_i64, c_p]),
+    "rflu_getrf_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_int, c_i64, c_p]),
+    "rflu_getrf_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_int, c_i64, c_p]),
+    "rflu_panel_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_int, c_p]),
+    "rflu_laswp_rm_{s}_dev": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64]),
+    "rflu_trsm_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64]),
+    "rflu_gemm_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64]),
+    "rflu_cm_to_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64]),
+    "rflu_rm_to_cm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64]),
+    "rflu_fill_uniform_{s}_dev": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_u64, c_i64, c_i64, c_i64, c_dbl]),
+}
+_PLAIN = {
+    "rflu_create": (c_int, [ctypes.POINTER(c_p), c_int]),
+    "rflu_destroy": (c_int, [c_p]),
+    "rflu_last_error": (ctypes.c_char_p, []),
+    "rflu_version": (c_int, []),
+    "rflu_set_stream": (c_int, [c_p, c_p]),
+    "rflu_synchronize": (c_int, [c_p]),
+    "rflu_last_path": (c_int, [c_p]),
+    "rflu_profile_enable": (c_int, [c_p, c_int]),
+    "rflu_profile_get": (c_int, [c_p, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
+}
+
+EXPORTS = dict(_PLAIN)
+for _k, _v in _TYPED.items():
+    for _s in ("f64", "f32"):
+        EXPORTS[_k.format(s=_s)] = _v
+
+K_GEMM, K_TRSM, K_LASWP, K_PANEL, K_TRANSPOSE, K_MISC = range(6)
+KCLASS_NAMES = ["gemm", "trsm", "laswp", "panel", "transpose", "misc"]
+PATH_NONE, PATH_HIP_RECURSIVE, PATH_HIP_BLOCKED = 0, 1, 2
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen librflu.so and declare every prototype.  Raises RfluError if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RfluError(
+                f"{LIB_PATH} is missing: build the HIP library first "
+                "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = load().rflu_last_error()
+        raise RfluError(f"librflu status {status}: {msg.decode() if msg else ''}")
+
+
+class Handle:
+    """One device, one stream, reusable workspaces (the analogue of a LinearSolve cache)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        self.ptr = c_p()
+        check(self.lib.rflu_create(ctypes.byref(self.ptr), int(device)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            self.lib.rflu_destroy(self.ptr)
+            self.ptr = c_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def call(self, name: str, *args):
+        check(getattr(self.lib, name)(self.ptr, *args))
+
+    def last_path(self) -> int:
+        return int(self.lib.rflu_last_path(self.ptr))
+
+    def set_stream(self, stream_ptr: int | None):
+        check(self.lib.rflu_set_stream(self.ptr, c_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        check(self.lib.rflu_synchronize(self.ptr))
+
+    def profile_enable(self, on: bool):
+        check(self.lib.rflu_profile_enable(self.ptr, int(bool(on))))
+
+    def profile(self) -> dict:
+        out = {}
+        for k, name in enumerate(KCLASS_NAMES):
+            ms, n, work = c_dbl(), c_i64(), c_dbl()
+            check(self.lib.rflu_profile_get(self.ptr, k, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(work)))
+            out[name] = {"ms": ms.value, "launches": n.value, "work": work.value}
+        return out
+
+
+_handles: dict[int, Handle] = {}
+
+
+def default_handle(device: int = 0) -> Handle:
+    if device not in _handles:
+        _handles[device] = Handle(device)
+    return _handles[device]

@@ -1,0 +1,83 @@
+"""Builds librflu.so (hand-written HIP for gfx950) in-tree with hipcc.  No JIT cache, no other targets."""
+from __future__ import annotations
+
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "librflu.so")
+SOURCES = ["gemm.hip", "panel.hip", "trsm.hip", "laswp.hip", "driver.cpp"]
+HEADERS = ["rflu_internal.hpp", os.path.join("..", "..", "include", "rflu.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _digest(paths):
+    """Content hash of the sources (mtimes do not survive the copy to the GPU box)."""
+    import hashlib
+
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build_librflu(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs, stamps = [], {}
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        stamp = op + ".sha1"
+        want = _digest([sp, *hdrs])
+        have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+        if force or not os.path.exists(op) or have != want:
+            jobs.append((sp, op))
+            stamps[op] = (stamp, want)
+
+    def compile_one(job):
+        sp, op = job
+        cmd = [_hipcc(), *FLAGS, "-c", sp, "-o", op]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {sp}:\n{r.stdout}\n{r.stderr}")
+        stamp, want = stamps[op]
+        with open(stamp, "w") as f:
+            f.write(want)
+        return op
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(compile_one, jobs))
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    if force or jobs or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+
+    print(build_librflu(force="--force" in sys.argv, verbose=True))

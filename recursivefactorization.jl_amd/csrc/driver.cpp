@@ -1,0 +1,424 @@
+// driver.cpp -- host side of librflu.so: handle, the Toledo recursion, and the C ABI of include/rflu.h.
+//
+// Host control flow restates /root/reference/src/lu.jl:
+//   lu!(A, ipiv, pivot, thread; ...)  (:97-130)  -> rflu_getrf_* : NoPivot identity fill (:111-113), recursion, info
+//   _recurse! fat-matrix tail         (:148-154) -> getrf_rm(): TRSM of the columns right of the square part
+//   reckernel!                        (:189-263) -> rec(): factor left half, TRSM, Schur GEMM, factor right half
+// MI355X-specific re-scheduling (results unchanged):
+//   * leaves are 64 columns wide (one cooperative panel kernel, panel.hip) and the split is on 64-column boundaries
+//     (the reference's nsplit, :158-162, rounds to 64 BYTES of column; SURVEY.md a2: "GPU picks its own split");
+//   * the interchanges of a leaf are applied to ALL other columns right after the leaf (one full-width, perfectly
+//     parallel laswp launch) instead of level by level (:233, :246) -- the same swaps in the same order on data that
+//     nothing touches in between, hence identical results with log2(N/64) times fewer dependent launches;
+//   * ipiv is written with global 1-based rows directly (the reference reaches the same values through P2 .+= n1,
+//     :256-260) and info is the global index of the first zero pivot (the reference's offset fix-up :248-255).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "rflu_internal.hpp"
+
+namespace rflu {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+static int ensure_buffer(void** ptr, size_t* cap, size_t need)
+{
+    if (*cap >= need) return RFLU_OK;
+    if (*ptr) RFLU_HIP(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    RFLU_HIP(hipMalloc(ptr, need));
+    *cap = need;
+    return RFLU_OK;
+}
+
+int ensure_bookkeeping(Handle* h, int64_t rows)
+{
+    const int64_t chunks = (rows + NB - 1) / NB + 1;
+    if (chunks <= h->pm_chunks) return RFLU_OK;
+    if (h->pm_cnt) RFLU_HIP(hipFree(h->pm_cnt));
+    if (h->pm_dst) RFLU_HIP(hipFree(h->pm_dst));
+    if (h->pm_src) RFLU_HIP(hipFree(h->pm_src));
+    h->pm_cnt = h->pm_dst = h->pm_src = nullptr;
+    h->pm_chunks = 0;
+    RFLU_HIP(hipMalloc((void**)&h->pm_cnt, (size_t)chunks * sizeof(int)));
+    RFLU_HIP(hipMalloc((void**)&h->pm_dst, (size_t)chunks * 2 * NB * sizeof(int)));
+    RFLU_HIP(hipMalloc((void**)&h->pm_src, (size_t)chunks * 2 * NB * sizeof(int)));
+    RFLU_HIP(hipMemset(h->pm_cnt, 0, (size_t)chunks * sizeof(int)));
+    h->pm_chunks = chunks;
+    return RFLU_OK;
+}
+
+// ---- B <- L^-1 B by recursive splitting on 64-row boundaries (off-diagonal work = MFMA GEMM) -----------------------
+template <typename T>
+static int trsm_rec(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t ldl, T* B, int64_t ldb)
+{
+    if (n <= 0 || nrhs <= 0) return RFLU_OK;
+    if (n <= NB) return launch_trsm_base<T>(h, n, nrhs, L, ldl, B, ldb);
+    const int64_t leaves = (n + NB - 1) / NB;
+    const int64_t n1 = ((leaves + 1) / 2) * NB;
+    RFLU_TRY(trsm_rec<T>(h, n1, nrhs, L, ldl, B, ldb));
+    RFLU_TRY(launch_gemm<T>(h, n - n1, nrhs, n1, L + n1 * ldl, ldl, B, ldb, B + n1 * ldb, ldb));
+    return trsm_rec<T>(h, n - n1, nrhs, L + n1 * ldl + n1, ldl, B + n1 * ldb, ldb);
+}
+
+template <typename T>
+struct Fact {
+    Handle* h;
+    T* R;
+    int64_t ld, m, n;  // full matrix: m rows, n columns
+    int64_t* ipiv;
+    int pivot;
+
+    // leaf: rows [c0, m), columns [c0, c0+w): cooperative panel + the interchanges on every other column
+    int leaf(int64_t c0, int64_t w)
+    {
+        RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, ipiv, pivot));
+        if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, 0, c0, c0 + w, n - (c0 + w), c0 / NB, c0 / NB + 1));
+        return RFLU_OK;
+    }
+
+    // reckernel! (src/lu.jl:189-263) on columns [c0, c1), rows [c0, m)
+    int rec(int64_t c0, int64_t c1)
+    {
+        const int64_t w = c1 - c0;
+        if (w <= 0) return RFLU_OK;
+        if (w <= NB) return leaf(c0, w);
+        const int64_t leaves = (w + NB - 1) / NB;
+        const int64_t n1 = ((leaves + 1) / 2) * NB;
+        const int64_t cm = c0 + n1;
+        RFLU_TRY(rec(c0, cm));
+        T* A11 = R + c0 * ld + c0;
+        T* A12 = R + c0 * ld + cm;
+        T* A21 = R + cm * ld + c0;
+        T* A22 = R + cm * ld + cm;
+        RFLU_TRY(trsm_rec<T>(h, n1, c1 - cm, A11, ld, A12, ld));                        // src/lu.jl:235
+        RFLU_TRY(launch_gemm<T>(h, m - cm, c1 - cm, n1, A21, ld, A12, ld, A22, ld));    // src/lu.jl:240
+        return rec(cm, c1);
+    }
+};
+
+// Factor the row-major m x n matrix R in place.  blocksize <= 0: pure recursion; else right-looking over block columns.
+template <typename T>
+static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* ipiv, int pivot, int64_t blocksize,
+                    int64_t* info)
+{
+    if (m < 0 || n < 0 || ld < std::max<int64_t>(n, 1) || (m > 0 && n > 0 && R == nullptr)) {
+        set_error("getrf: bad arguments m=%lld n=%lld ld=%lld", (long long)m, (long long)n, (long long)ld);
+        return RFLU_ERR_ARG;
+    }
+    if (pivot && ipiv == nullptr && std::min(m, n) > 0) {
+        set_error("getrf: pivot != 0 needs an ipiv buffer");
+        return RFLU_ERR_ARG;
+    }
+    *info = 0;
+    const int64_t mn = std::min(m, n);
+    h->last_path = RFLU_PATH_NONE;
+    if (mn == 0) return RFLU_OK;
+    RFLU_TRY(ensure_bookkeeping(h, m));
+    RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), h->stream));
+    if (!pivot && ipiv) RFLU_TRY(launch_iota_ipiv(h, ipiv, 0, mn));  // src/lu.jl:111-113
+
+    Fact<T> f{h, R, ld, m, n, ipiv, pivot};
+    if (blocksize <= 0 || blocksize >= mn) {
+        h->last_path = RFLU_PATH_HIP_RECURSIVE;
+        RFLU_TRY(f.rec(0, mn));
+    } else {
+        h->last_path = RFLU_PATH_HIP_BLOCKED;
+        const int64_t bs = round_up(blocksize, NB);
+        for (int64_t j = 0; j < mn; j += bs) {
+            const int64_t jb = std::min(bs, mn - j);
+            RFLU_TRY(f.rec(j, j + jb));
+            const int64_t je = j + jb;
+            if (je < mn) {  // trailing update of the remaining square part
+                RFLU_TRY(trsm_rec<T>(h, jb, mn - je, R + j * ld + j, ld, R + j * ld + je, ld));
+                RFLU_TRY(launch_gemm<T>(h, m - je, mn - je, jb, R + je * ld + j, ld, R + j * ld + je, ld,
+                                        R + je * ld + je, ld));
+            }
+        }
+    }
+    if (m < n)  // fat matrix: AR <- L^-1 AR (src/lu.jl:148-154; the interchanges already reached these columns)
+        RFLU_TRY(trsm_rec<T>(h, m, n - m, R, ld, R + m, ld));
+
+    RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    RFLU_HIP(hipStreamSynchronize(h->stream));
+    if (h->info_pinned[1] != 0) {
+        set_error("cooperative panel kernel timed out waiting for a peer workgroup");
+        return RFLU_ERR_TIMEOUT;
+    }
+    *info = h->info_pinned[0];
+    return RFLU_OK;
+}
+
+// column-major device entry: R-layout workspace, transpose in, factor, transpose out
+template <typename T>
+static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv, int pivot,
+                        int64_t blocksize, int64_t* info)
+{
+    if (m < 0 || n < 0 || lda < std::max<int64_t>(m, 1) || info == nullptr) {
+        set_error("getrf: bad arguments m=%lld n=%lld lda=%lld", (long long)m, (long long)n, (long long)lda);
+        return RFLU_ERR_ARG;
+    }
+    *info = 0;
+    if (m == 0 || n == 0) return RFLU_OK;
+    const int64_t ldr = round_up(n, 16);
+    RFLU_TRY(ensure_buffer(&h->work, &h->work_bytes, (size_t)m * (size_t)ldr * sizeof(T)));
+    T* R = static_cast<T*>(h->work);
+    RFLU_TRY(launch_transpose<T>(h, m, n, A, lda, R, ldr));
+    RFLU_TRY(getrf_rm<T>(h, m, n, R, ldr, ipiv, pivot, blocksize, info));
+    RFLU_TRY(launch_transpose<T>(h, n, m, R, ldr, A, lda));
+    RFLU_HIP(hipStreamSynchronize(h->stream));
+    return RFLU_OK;
+}
+
+// host entry: stage through device buffers owned by the handle
+template <typename T>
+static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv, int pivot, int64_t blocksize,
+                      int64_t* info)
+{
+    if (m < 0 || n < 0 || lda < std::max<int64_t>(m, 1) || info == nullptr || (m > 0 && n > 0 && A == nullptr)) {
+        set_error("getrf: bad arguments m=%lld n=%lld lda=%lld", (long long)m, (long long)n, (long long)lda);
+        return RFLU_ERR_ARG;
+    }
+    *info = 0;
+    const int64_t mn = std::min(m, n);
+    if (mn == 0) return RFLU_OK;
+    RFLU_TRY(ensure_buffer(&h->hostA_dev, &h->hostA_bytes, (size_t)m * (size_t)n * sizeof(T)));
+    if ((size_t)mn > h->ipiv_cap) {
+        if (h->ipiv_dev) RFLU_HIP(hipFree(h->ipiv_dev));
+        h->ipiv_dev = nullptr;
+        h->ipiv_cap = 0;
+        RFLU_HIP(hipMalloc((void**)&h->ipiv_dev, (size_t)mn * sizeof(int64_t)));
+        h->ipiv_cap = (size_t)mn;
+    }
+    T* dA = static_cast<T*>(h->hostA_dev);
+    RFLU_HIP(hipMemcpy2DAsync(dA, (size_t)m * sizeof(T), A, (size_t)lda * sizeof(T), (size_t)m * sizeof(T), (size_t)n,
+                              hipMemcpyHostToDevice, h->stream));
+    const bool want_ipiv = (ipiv != nullptr);
+    RFLU_TRY(getrf_cm_dev<T>(h, m, n, dA, m, (pivot || want_ipiv) ? h->ipiv_dev : nullptr, pivot, blocksize, info));
+    RFLU_HIP(hipMemcpy2DAsync(A, (size_t)lda * sizeof(T), dA, (size_t)m * sizeof(T), (size_t)m * sizeof(T), (size_t)n,
+                              hipMemcpyDeviceToHost, h->stream));
+    if (want_ipiv)
+        RFLU_HIP(hipMemcpyAsync(ipiv, h->ipiv_dev, (size_t)mn * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    RFLU_HIP(hipStreamSynchronize(h->stream));
+    return RFLU_OK;
+}
+
+}  // namespace rflu
+
+using namespace rflu;
+
+static Handle* H(rflu_handle_t h) { return reinterpret_cast<Handle*>(h); }
+
+#define CHECK_HANDLE(h)                        \
+    do {                                       \
+        if ((h) == nullptr) {                  \
+            set_error("null handle");          \
+            return RFLU_ERR_ARG;               \
+        }                                      \
+        RFLU_HIP(hipSetDevice(H(h)->device));  \
+    } while (0)
+
+extern "C" {
+
+int rflu_version(void) { return 100; }
+
+const char* rflu_last_error(void) { return g_err; }
+
+int rflu_create(rflu_handle_t* handle, int device)
+{
+    if (handle == nullptr) { set_error("null handle pointer"); return RFLU_ERR_ARG; }
+    *handle = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible (this library has no CPU fallback)");
+        return RFLU_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return RFLU_ERR_ARG; }
+    RFLU_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RFLU_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; librflu is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return RFLU_ERR_NODEVICE;
+    }
+    Handle* h = new (std::nothrow) Handle();
+    if (!h) { set_error("out of host memory"); return RFLU_ERR_ARG; }
+    h->device = device;
+    h->num_cus = prop.multiProcessorCount;
+    RFLU_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    RFLU_HIP(hipMalloc((void**)&h->info_dev, 2 * sizeof(int64_t)));
+    RFLU_HIP(hipHostMalloc((void**)&h->info_pinned, 2 * sizeof(int64_t)));
+    h->pscratch_bytes = panel_scratch_bytes();
+    RFLU_HIP(hipMalloc((void**)&h->pscratch, h->pscratch_bytes));
+    RFLU_HIP(hipMemset(h->pscratch, 0, h->pscratch_bytes));
+    RFLU_HIP(hipEventCreate(&h->ev0));
+    RFLU_HIP(hipEventCreate(&h->ev1));
+    *handle = reinterpret_cast<rflu_handle_t>(h);
+    return RFLU_OK;
+}
+
+int rflu_destroy(rflu_handle_t handle)
+{
+    if (!handle) return RFLU_OK;
+    Handle* h = H(handle);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->work) (void)hipFree(h->work);
+    if (h->ipiv_dev) (void)hipFree(h->ipiv_dev);
+    if (h->hostA_dev) (void)hipFree(h->hostA_dev);
+    if (h->pm_cnt) (void)hipFree(h->pm_cnt);
+    if (h->pm_dst) (void)hipFree(h->pm_dst);
+    if (h->pm_src) (void)hipFree(h->pm_src);
+    if (h->pscratch) (void)hipFree(h->pscratch);
+    if (h->info_dev) (void)hipFree(h->info_dev);
+    if (h->info_pinned) (void)hipHostFree(h->info_pinned);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return RFLU_OK;
+}
+
+int rflu_set_stream(rflu_handle_t handle, void* hip_stream)
+{
+    CHECK_HANDLE(handle);
+    H(handle)->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : H(handle)->own_stream;
+    return RFLU_OK;
+}
+
+int rflu_synchronize(rflu_handle_t handle)
+{
+    CHECK_HANDLE(handle);
+    RFLU_HIP(hipStreamSynchronize(H(handle)->stream));
+    return RFLU_OK;
+}
+
+int rflu_last_path(rflu_handle_t handle) { return handle ? H(handle)->last_path : RFLU_PATH_NONE; }
+
+#define DEFINE_TYPED(SFX, T)                                                                                          \
+    int rflu_getrf_##SFX(rflu_handle_t handle, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv, int pivot,     \
+                         int64_t blocksize, int64_t* info)                                                            \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        return getrf_host<T>(H(handle), m, n, A, lda, ipiv, pivot, blocksize, info);                                  \
+    }                                                                                                                 \
+    int rflu_getrf_##SFX##_dev(rflu_handle_t handle, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv,          \
+                               int pivot, int64_t blocksize, int64_t* info)                                           \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        return getrf_cm_dev<T>(H(handle), m, n, A, lda, ipiv, pivot, blocksize, info);                                \
+    }                                                                                                                 \
+    int rflu_getrf_rm_##SFX##_dev(rflu_handle_t handle, int64_t m, int64_t n, T* R, int64_t ld, int64_t* ipiv,        \
+                                  int pivot, int64_t blocksize, int64_t* info)                                        \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        if (info == nullptr) { set_error("null info"); return RFLU_ERR_ARG; }                                         \
+        return getrf_rm<T>(H(handle), m, n, R, ld, ipiv, pivot, blocksize, info);                                     \
+    }                                                                                                                 \
+    int rflu_panel_rm_##SFX##_dev(rflu_handle_t handle, int64_t m, int64_t r0, int64_t c0, int64_t w, T* R,           \
+                                  int64_t ld, int64_t* ipiv, int pivot, int64_t* info)                                \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        Handle* h = H(handle);                                                                                        \
+        if (info == nullptr || w < 0 || r0 < 0 || c0 < 0 || m < r0 + w) { set_error("panel: bad arguments"); return RFLU_ERR_ARG; } \
+        RFLU_TRY(ensure_bookkeeping(h, m));                                                                           \
+        RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), h->stream));                                     \
+        if (!pivot && ipiv) RFLU_TRY(launch_iota_ipiv(h, ipiv, r0, w));                                               \
+        /* wide panels are factored by the same recursion, restricted to columns [c0, c0+w) with diagonal at r0 */   \
+        for (int64_t j = 0; j < w; j += NB) {                                                                         \
+            const int64_t jb = std::min<int64_t>(NB, w - j);                                                          \
+            if (j > 0) {                                                                                              \
+                RFLU_TRY(trsm_rec<T>(h, j, jb, R + r0 * ld + c0, ld, R + r0 * ld + c0 + j, ld));                      \
+                RFLU_TRY(launch_gemm<T>(h, m - r0 - j, jb, j, R + (r0 + j) * ld + c0, ld, R + r0 * ld + c0 + j, ld,   \
+                                        R + (r0 + j) * ld + c0 + j, ld));                                             \
+            }                                                                                                         \
+            RFLU_TRY(launch_panel<T>(h, R, ld, m, r0 + j, c0 + j, jb, ipiv, pivot));                                  \
+            if (pivot)                                                                                                \
+                RFLU_TRY(launch_laswp2<T>(h, R, ld, c0, j, c0 + j + jb, w - j - jb, (r0 + j) / NB, (r0 + j) / NB + 1)); \
+        }                                                                                                             \
+        RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); \
+        RFLU_HIP(hipStreamSynchronize(h->stream));                                                                    \
+        if (h->info_pinned[1] != 0) { set_error("cooperative panel kernel timed out"); return RFLU_ERR_TIMEOUT; }     \
+        *info = h->info_pinned[0];                                                                                    \
+        return RFLU_OK;                                                                                               \
+    }                                                                                                                 \
+    int rflu_laswp_rm_##SFX##_dev(rflu_handle_t handle, T* R, int64_t ld, int64_t m, int64_t c0, int64_t ncols,       \
+                                  const int64_t* ipiv, int64_t k0, int64_t k1)                                        \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        if (k0 % NB != 0 || k1 < k0) { set_error("laswp: k0 must be a multiple of 64"); return RFLU_ERR_ARG; }        \
+        RFLU_TRY(ensure_bookkeeping(H(handle), std::max(m, k1)));                                                     \
+        RFLU_TRY(launch_perm_build(H(handle), ipiv, k0, k1, m));                                                      \
+        return launch_laswp<T>(H(handle), R, ld, c0, ncols, k0 / NB, (k1 + NB - 1) / NB);                             \
+    }                                                                                                                 \
+    int rflu_trsm_rm_##SFX##_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, const T* L, int64_t ldl, T* B,        \
+                                 int64_t ldb)                                                                         \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        return trsm_rec<T>(H(handle), n, nrhs, L, ldl, B, ldb);                                                       \
+    }                                                                                                                 \
+    int rflu_gemm_rm_##SFX##_dev(rflu_handle_t handle, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda,      \
+                                 const T* B, int64_t ldb, T* C, int64_t ldc)                                          \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        return launch_gemm<T>(H(handle), M, N, K, A, lda, B, ldb, C, ldc);                                            \
+    }                                                                                                                 \
+    int rflu_cm_to_rm_##SFX##_dev(rflu_handle_t handle, int64_t m, int64_t n, const T* A, int64_t lda, T* R,          \
+                                  int64_t ldr)                                                                        \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        return launch_transpose<T>(H(handle), m, n, A, lda, R, ldr);                                                  \
+    }                                                                                                                 \
+    int rflu_rm_to_cm_##SFX##_dev(rflu_handle_t handle, int64_t m, int64_t n, const T* R, int64_t ldr, T* A,          \
+                                  int64_t lda)                                                                        \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        return launch_transpose<T>(H(handle), n, m, R, ldr, A, lda);                                                  \
+    }                                                                                                                 \
+    int rflu_fill_uniform_##SFX##_dev(rflu_handle_t handle, T* A, int64_t m, int64_t n, int64_t ld, int row_major,    \
+                                      uint64_t seed, int64_t M_global, int64_t i0, int64_t j0, double diag_add)       \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        return launch_fill_uniform<T>(H(handle), A, m, n, ld, row_major, seed, M_global, i0, j0, diag_add);           \
+    }
+
+DEFINE_TYPED(f64, double)
+DEFINE_TYPED(f32, float)
+
+int rflu_profile_enable(rflu_handle_t handle, int enable)
+{
+    CHECK_HANDLE(handle);
+    Handle* h = H(handle);
+    h->prof = enable != 0;
+    for (int k = 0; k < RFLU_K_COUNT; ++k) h->slots[k] = ProfSlot();
+    return RFLU_OK;
+}
+
+int rflu_profile_get(rflu_handle_t handle, int kclass, double* ms, int64_t* launches, double* work)
+{
+    CHECK_HANDLE(handle);
+    if (kclass < 0 || kclass >= RFLU_K_COUNT) { set_error("bad kernel class %d", kclass); return RFLU_ERR_ARG; }
+    const ProfSlot& s = H(handle)->slots[kclass];
+    if (ms) *ms = s.ms;
+    if (launches) *launches = s.launches;
+    if (work) *work = s.work;
+    return RFLU_OK;
+}
+
+}  // extern "C"

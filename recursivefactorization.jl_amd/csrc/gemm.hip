@@ -1,0 +1,225 @@
+// gemm.hip -- trailing update  C <- C - A*B  on the MFMA matrix cores of gfx950 (CDNA4).
+//
+// Replaces schur_complement! (/root/reference/src/lu.jl:265-284: C[m,n] = (0 - sum_k A[m,k]*B[k,n]) + C[m,n]) and
+// supplies the off-diagonal work of the recursive TRSM (src/lu.jl:235).  Dominant kernel of the path: N^3/2 of the
+// 2N^3/3 LU flops plus ~90 % of the TRSM's N^3/6.
+//
+// Shape: all operands row-major (R layout).  One workgroup = 256 threads = 4 waves computes a 128x128 tile of C; each
+// wave owns a 64x64 sub-tile as 4x4 MFMA fragments of 16x16 (v_mfma_f64_16x16x4_f64, or v_mfma_f32_16x16x4_f32 for
+// Float32 -- both take ONE scalar per lane for A and B).  K is walked in slabs of 16 through a double-buffered LDS
+// image (one barrier per slab): global loads for slab t+1 are issued before the 64 MFMAs of slab t and written to the
+// other LDS buffer after them, so HBM/L2 latency hides behind ~4096 cycles of matrix work per wave.
+//
+// LDS images (strides chosen so every fragment read is bank-conflict free, MI355X_MICROARCH.md "LDS"):
+//   As[i][k], row stride SA = BK+2 : lanes (i=l&15, k=l>>4) of a 32-lane group hit 32 distinct 8-byte bank pairs
+//   Bs[k][j], row stride SB = BN+16: the two k-rows read by a 32-lane group sit 32 banks apart
+// Two workgroups per CU (2 x 72 KiB LDS, <=256 VGPRs) keep each SIMD's matrix pipe fed across barriers.
+//
+// Roofline: bound = fp64 MFMA, 78.6 TFLOP/s chip peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz);
+// algorithmic work 2*M*N*K flops per launch.
+#include "rflu_internal.hpp"
+
+namespace rflu {
+
+template <typename T>
+struct Mfma;
+
+template <>
+struct Mfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // f64 C/D fragment: col = lane & 15, row = (lane >> 4) + 4*r   (cdna_hip_programming.md section 3)
+    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+
+template <>
+struct Mfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // f32 C/D fragment: col = lane & 15, row = 4*(lane >> 4) + r
+    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+constexpr int G_BM = 128, G_BN = 128, G_BK = 16;
+constexpr int G_SA = G_BK + 2;
+constexpr int G_SB = G_BN + 16;
+constexpr int G_STAGE = G_BM * G_SA + G_BK * G_SB;  // elements per LDS stage
+constexpr int G_GROUP_M = 8;                        // tile rows walked together (L2 reuse of the B panel)
+
+template <typename T>
+struct GemmArgs {
+    int M, N, K;
+    const T* A;
+    int64_t lda;
+    const T* B;
+    int64_t ldb;
+    T* C;
+    int64_t ldc;
+    int tiles_m, tiles_n;
+    int vec_ok;  // operands 16-byte aligned with even strides: full tiles may use 16-byte loads
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
+{
+    typedef typename Mfma<T>::acc_t acc_t;
+    constexpr int VW = 16 / (int)sizeof(T);  // elements per 16-byte vector
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- workgroup -> tile: bijective XCD-aware remap (block b runs on XCD b % 8; give each XCD a contiguous range
+    // of tiles so neighbours share operand panels in that XCD's private L2), then GROUP_M-row grouped ordering.
+    int tile_m, tile_n;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        const int per_group = G_GROUP_M * g.tiles_n;
+        const int group = wg / per_group;
+        const int first_m = group * G_GROUP_M;
+        const int gsz = min(g.tiles_m - first_m, G_GROUP_M);
+        const int in_group = wg - group * per_group;
+        tile_m = first_m + in_group % gsz;
+        tile_n = in_group / gsz;
+    }
+    const int m0 = tile_m * G_BM, n0 = tile_n * G_BN;
+
+    // ---- global -> register staging map: A slab 128x16 (8 consecutive k per thread), B slab 16x128 (8 consecutive j)
+    const int a_row = tid >> 1, a_kb = (tid & 1) * 8;
+    const int b_k = tid >> 4, b_jb = (tid & 15) * 8;
+    const T* Ap = g.A + (int64_t)(m0 + a_row) * g.lda + a_kb;
+    const T* Bp = g.B + (int64_t)b_k * g.ldb + n0 + b_jb;
+    const bool a_row_ok = (m0 + a_row) < g.M;
+    const bool full_mn = g.vec_ok && (m0 + G_BM <= g.M) && (n0 + G_BN <= g.N);
+
+    T ra[8], rb[8];
+
+    auto gload = [&](int k0) {
+        if (full_mn && (k0 + G_BK <= g.K)) {
+#pragma unroll
+            for (int v = 0; v < 8 / VW; ++v) {
+                vec_t x = *reinterpret_cast<const vec_t*>(Ap + k0 + v * VW);
+                vec_t y = *reinterpret_cast<const vec_t*>(Bp + (int64_t)k0 * g.ldb + v * VW);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    ra[v * VW + e] = x[e];
+                    rb[v * VW + e] = y[e];
+                }
+            }
+        } else {
+            const bool bk_ok = (k0 + b_k) < g.K;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ra[e] = (a_row_ok && (k0 + a_kb + e) < g.K) ? Ap[k0 + e] : T(0);
+                rb[e] = (bk_ok && (n0 + b_jb + e) < g.N) ? Bp[(int64_t)k0 * g.ldb + e] : T(0);
+            }
+        }
+    };
+    auto sstore = [&](int stage) {
+        T* As = smem + stage * G_STAGE;
+        T* Bs = As + G_BM * G_SA;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            As[a_row * G_SA + a_kb + e] = ra[e];
+            Bs[b_k * G_SB + b_jb + e] = rb[e];
+        }
+    };
+
+    acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{T(0), T(0), T(0), T(0)};
+
+    const int nk = (g.K + G_BK - 1) / G_BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    const int a_frag = (wr * 64 + (lane & 15)) * G_SA + (lane >> 4);
+    const int b_frag = (lane >> 4) * G_SB + wc * 64 + (lane & 15);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * G_BK);
+        const T* As = smem + cur * G_STAGE;
+        const T* Bs = As + G_BM * G_SA;
+#pragma unroll
+        for (int kk = 0; kk < G_BK / 4; ++kk) {
+            T a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = As[a_frag + t * 16 * G_SA + kk * 4];
+                b[t] = Bs[b_frag + kk * 4 * G_SB + t * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C <- C - acc.  For a fixed (i,j,r) sixteen lanes cover 16 consecutive columns of one row.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wr * 64 + i * 16 + Mfma<T>::crow(lane, r);
+            if (row < g.M) {
+                T* crow_p = g.C + (int64_t)row * g.ldc + n0 + wc * 64 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+                    if (col < g.N) crow_p[j * 16] = crow_p[j * 16] - acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C,
+                int64_t ldc)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return RFLU_OK;
+    GemmArgs<T> g;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.tiles_m = (int)((M + G_BM - 1) / G_BM);
+    g.tiles_n = (int)((N + G_BN - 1) / G_BN);
+    constexpr int VW = 16 / (int)sizeof(T);
+    g.vec_ok = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0) && (lda % VW == 0) &&
+               (ldb % VW == 0);
+    const size_t lds = 2 * (size_t)G_STAGE * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RFLU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sub_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    ProfScope ps(h, RFLU_K_GEMM, 2.0 * (double)M * (double)N * (double)K);
+    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n;
+    hipLaunchKernelGGL(gemm_sub_kernel<T>, dim3((unsigned)nwg), dim3(256), lds, h->stream, g);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+template int launch_gemm<double>(Handle*, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t,
+                                 double*, int64_t);
+template int launch_gemm<float>(Handle*, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*,
+                                int64_t);
+
+}  // namespace rflu

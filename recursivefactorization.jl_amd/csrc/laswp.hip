@@ -1,0 +1,187 @@
+// laswp.hip -- row interchanges, the internal layout change, and small utilities.
+//
+// apply_permutation! (/root/reference/src/lu.jl:164-188) swaps row i with row P[i] sequentially for every pivot of a
+// block.  Here a chunk of up to 64 sequential interchanges has already been folded (panel.hip: perm_build_wave) into an
+// equivalent list of at most 128 independent row MOVES  new[dst[e]] = old[src[e]], so the kernel is a pure gather /
+// scatter of contiguous row segments in the row-major R layout: each wave reads 64 consecutive columns (512 B for
+// Float64) of a source row, all reads of a chunk are issued before the first write (one barrier), and every pivot
+// costs exactly its algorithmic 4*sizeof(T) bytes per column of HBM traffic -- no cache-line amplification.
+// Roofline: HBM (8 TB/s spec, ~6.3 TB/s achievable); algorithmic bytes per launch = 4*sizeof(T)*ncols*pivots.
+#include "rflu_internal.hpp"
+
+namespace rflu {
+
+constexpr int LW_COLS = 64;           // columns per workgroup (one lane per column)
+constexpr int LW_ROWS_PER_THREAD = (2 * NB) / 4;  // 4 waves share the <=128 moves of a chunk
+
+template <typename T>
+__global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA,
+                                                    int64_t c1, int64_t ncolsB, const int* __restrict__ pm_cnt,
+                                                    const int* __restrict__ pm_dst, const int* __restrict__ pm_src,
+                                                    int chunk0, int chunk1)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // two column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB) are covered by one launch (left and right of a panel)
+    const int64_t blocksA = (ncolsA + LW_COLS - 1) / LW_COLS;
+    int64_t col;
+    bool active;
+    if ((int64_t)blockIdx.x < blocksA) {
+        const int64_t off = (int64_t)blockIdx.x * LW_COLS + lane;
+        col = c0 + off;
+        active = off < ncolsA;
+    } else {
+        const int64_t off = ((int64_t)blockIdx.x - blocksA) * LW_COLS + lane;
+        col = c1 + off;
+        active = off < ncolsB;
+    }
+    T v[LW_ROWS_PER_THREAD];
+    for (int t = chunk0; t < chunk1; ++t) {
+        const int cnt = pm_cnt[t];
+        const int* dst = pm_dst + (size_t)t * 2 * NB;
+        const int* src = pm_src + (size_t)t * 2 * NB;
+#pragma unroll
+        for (int i = 0; i < LW_ROWS_PER_THREAD; ++i) {
+            const int e = wave + 4 * i;
+            if (e < cnt && active) v[i] = R[(int64_t)src[e] * ld + col];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LW_ROWS_PER_THREAD; ++i) {
+            const int e = wave + 4 * i;
+            if (e < cnt && active) R[(int64_t)dst[e] * ld + col] = v[i];
+        }
+        __syncthreads();
+    }
+}
+
+// Apply chunks [chunk0, chunk1) to the column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB).
+template <typename T>
+int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t chunk0,
+                  int64_t chunk1)
+{
+    if (ncolsA < 0) ncolsA = 0;
+    if (ncolsB < 0) ncolsB = 0;
+    if (chunk1 <= chunk0 || ncolsA + ncolsB == 0) return RFLU_OK;
+    const int64_t blocks = (ncolsA + LW_COLS - 1) / LW_COLS + (ncolsB + LW_COLS - 1) / LW_COLS;
+    ProfScope ps(h, RFLU_K_LASWP,
+                 4.0 * sizeof(T) * (double)(ncolsA + ncolsB) * (double)NB * (double)(chunk1 - chunk0));
+    hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, h->stream, R, ld, c0, ncolsA, c1, ncolsB,
+                       h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk0, (int)chunk1);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+template <typename T>
+int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t chunk0, int64_t chunk1)
+{
+    return launch_laswp2<T>(h, R, ld, c0, ncols, 0, 0, chunk0, chunk1);
+}
+
+template int launch_laswp<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t);
+template int launch_laswp<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t);
+template int launch_laswp2<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
+template int launch_laswp2<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
+
+// ---- tiled transpose: out[r][c] = in[c][r]; "rows_out x cols_out" is the shape of `out` seen as row-major ------------
+// Used for column-major <-> R layout: a column-major m x n matrix (lda) IS a row-major n x m matrix (ld = lda).
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_kernel(int64_t rows_out, int64_t cols_out, const T* __restrict__ in,
+                                                        int64_t ld_in, T* __restrict__ out, int64_t ld_out)
+{
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    // read in[c0 + i][r0 + tx] (coalesced along in's rows)
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t ir = c0 + i, ic = r0 + tx;
+        tile[i][tx] = (ir < cols_out && ic < rows_out) ? in[ir * ld_in + ic] : T(0);
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t orow = r0 + i, ocol = c0 + tx;
+        if (orow < rows_out && ocol < cols_out) out[orow * ld_out + ocol] = tile[tx][i];
+    }
+}
+
+template <typename T>
+int launch_transpose(Handle* h, int64_t rows_out, int64_t cols_out, const T* in, int64_t ld_in, T* out, int64_t ld_out)
+{
+    if (rows_out <= 0 || cols_out <= 0) return RFLU_OK;
+    ProfScope ps(h, RFLU_K_TRANSPOSE, 2.0 * sizeof(T) * (double)rows_out * (double)cols_out);
+    dim3 grid((unsigned)((cols_out + 63) / 64), (unsigned)((rows_out + 63) / 64));
+    hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, h->stream, rows_out, cols_out, in, ld_in, out, ld_out);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+template int launch_transpose<double>(Handle*, int64_t, int64_t, const double*, int64_t, double*, int64_t);
+template int launch_transpose<float>(Handle*, int64_t, int64_t, const float*, int64_t, float*, int64_t);
+
+// ---- synthetic input: counter-based uniform [0,1), bit-identical to oracle/rflu_oracle.c:rfo_uniform01 -----------------
+__device__ __forceinline__ double uniform01(uint64_t seed, uint64_t ctr)
+{
+    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) fill_uniform_kernel(T* A, int64_t m, int64_t n, int64_t ld, int row_major,
+                                                           uint64_t seed, int64_t M_global, int64_t i0, int64_t j0,
+                                                           double diag_add)
+{
+    // fast index runs along the contiguous dimension of the destination
+    const int64_t fast = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t slow = blockIdx.y;
+    const int64_t i = row_major ? slow : fast;
+    const int64_t j = row_major ? fast : slow;
+    if (i >= m || j >= n) return;
+    const int64_t gi = i0 + i, gj = j0 + j;
+    double v = uniform01(seed, (uint64_t)(gj * M_global + gi));
+    T x = (T)v;
+    if (gi == gj) x = (T)(x + (T)diag_add);
+    A[row_major ? (i * ld + j) : (i + j * ld)] = x;
+}
+
+template <typename T>
+int launch_fill_uniform(Handle* h, T* A, int64_t m, int64_t n, int64_t ld, int row_major, uint64_t seed,
+                        int64_t M_global, int64_t i0, int64_t j0, double diag_add)
+{
+    if (m <= 0 || n <= 0) return RFLU_OK;
+    const int64_t fast = row_major ? n : m, slow = row_major ? m : n;
+    if (slow > 65535 * 1024LL) { set_error("fill: dimension too large"); return RFLU_ERR_ARG; }
+    ProfScope ps(h, RFLU_K_MISC, 0.0);
+    // gridDim.y is limited to 65535: loop over slabs of the slow dimension
+    for (int64_t s0 = 0; s0 < slow; s0 += 65535) {
+        const int64_t sn = (slow - s0 < 65535) ? (slow - s0) : 65535;
+        dim3 grid((unsigned)((fast + 255) / 256), (unsigned)sn);
+        T* base = A + (row_major ? s0 * ld : s0 * ld);
+        hipLaunchKernelGGL(fill_uniform_kernel<T>, grid, dim3(256), 0, h->stream, base, row_major ? sn : m,
+                           row_major ? n : sn, ld, row_major, seed, M_global, row_major ? i0 + s0 : i0,
+                           row_major ? j0 : j0 + s0, diag_add);
+    }
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+template int launch_fill_uniform<double>(Handle*, double*, int64_t, int64_t, int64_t, int, uint64_t, int64_t, int64_t,
+                                         int64_t, double);
+template int launch_fill_uniform<float>(Handle*, float*, int64_t, int64_t, int64_t, int, uint64_t, int64_t, int64_t,
+                                        int64_t, double);
+
+__global__ void iota_kernel(int64_t* ipiv, int64_t k0, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ipiv[k0 + i] = k0 + i + 1;
+}
+
+// identity pivots ipiv[k0 .. k0+n) = k0+1 .. k0+n  (NoPivot with a caller-supplied vector, src/lu.jl:111-113)
+int launch_iota_ipiv(Handle* h, int64_t* ipiv, int64_t k0, int64_t n)
+{
+    if (n <= 0 || ipiv == nullptr) return RFLU_OK;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, ipiv, k0, n);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+}  // namespace rflu

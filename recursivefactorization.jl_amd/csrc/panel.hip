@@ -1,0 +1,618 @@
+// panel.hip -- leaf panel factorization: the unblocked pivoted LU of a tall m x w block (w <= 64).
+//
+// Replaces _generic_lufact! (/root/reference/src/lu.jl:290-338) at the leaves of the Toledo recursion
+// (src/lu.jl:192-195).  Semantics kept: argmax |a_ik| over the not-yet-pivoted rows with strict '>' from 0
+// (zero/NaN column -> the row already in position k; ties -> lowest row position, src/lu.jl:298-305), row interchange,
+// reciprocal-multiply scaling (src/lu.jl:317-320), zero pivot -> record info once and keep updating (:321-334).
+//
+// MI355X design -- a latency problem, not a flop problem (w pivot steps, each a reduction over the whole column):
+//   * G = ceil(rows/256/RT) workgroups, all co-resident, one thread per matrix row, the row's w <= 64 entries live in
+//     REGISTERS for the whole kernel (fully unrolled column loop => static register indices).  The rank-1 updates
+//     therefore cost ~(w-k) FMAs per thread per step and no memory traffic at all.
+//   * rows never move: every thread tracks the current row POSITION of its row; an interchange just renames two
+//     positions.  Rows are written back to their final positions at the end (coalesced through an LDS transpose).
+//   * per step ONE cross-workgroup exchange: every workgroup publishes its candidate {position, row values k..w-1}
+//     as 8-byte data-tagged granules ({epoch tag, 32 payload bits}, relaxed agent-scope stores = sc1 write-through);
+//     wave 0 of every workgroup polls the G candidate headers, all arrive at the same winner, and read the winner's
+//     row (already published speculatively) -- no grid barrier, no fences, one hop
+//     (cdna_hip_programming.md Guideline 16 form R2; MI355X_MICROARCH.md "handoff-1to1").
+//     Records are double-buffered by step parity: a workgroup can be at most one step ahead of the slowest reader.
+//   * every spin is bounded; on timeout an error word is set and the host returns RFLU_ERR_TIMEOUT.
+//   * the last wave of workgroup 0 turns the w interchanges into a list of (dst,src) row moves for laswp.hip.
+// The NoPivot variant (Val(false)) needs no exchange at all: every workgroup factors the w x w top block redundantly in
+// LDS and then solves its own rows against U11.
+//
+// Roofline: neither HBM nor MFMA -- the bound is w x (one cross-CU hop, ~1-2 us).  Algorithmic work reported to the
+// timers: m*w^2 flops.
+#include "rflu_internal.hpp"
+
+namespace rflu {
+
+typedef unsigned long long u64;
+constexpr unsigned POS_NONE = 0x7fffffffu;
+constexpr int SPIN_LIMIT = 1 << 20;
+constexpr int TILE_LD = NB + 1;
+
+__device__ __forceinline__ void gran_store(u64* p, unsigned tag, unsigned v)
+{
+    __hip_atomic_store(p, ((u64)tag << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(const u64* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T>
+struct Gran;
+template <>
+struct Gran<double> {
+    static constexpr int N = 2;
+    static __device__ __forceinline__ void store(u64* p, unsigned tag, double v) {
+        const u64 b = (u64)__double_as_longlong(v);
+        gran_store(p, tag, (unsigned)(b >> 32));
+        gran_store(p + 1, tag, (unsigned)b);
+    }
+    static __device__ __forceinline__ bool load(const u64* p, unsigned tag, double& v) {
+        const u64 a = gran_load(p), b = gran_load(p + 1);
+        v = __longlong_as_double((long long)(((a & 0xffffffffull) << 32) | (b & 0xffffffffull)));
+        return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+    }
+};
+template <>
+struct Gran<float> {
+    static constexpr int N = 1;
+    static __device__ __forceinline__ void store(u64* p, unsigned tag, float v) { gran_store(p, tag, __float_as_uint(v)); }
+    static __device__ __forceinline__ bool load(const u64* p, unsigned tag, float& v) {
+        const u64 a = gran_load(p);
+        v = __uint_as_float((unsigned)a);
+        return (unsigned)(a >> 32) == tag;
+    }
+};
+
+// scratch layout (u64 words), per parity buffer b in {0,1}:
+//   hdr [b][g][4]        : {tag,pos}, a_pk granule(s), pad        -- polled by everybody
+//   row [b][g][NB*2]     : candidate row values, column j at word j*Gran::N
+constexpr size_t PS_HDR_WORDS = 4;
+constexpr size_t PS_ROW_WORDS = (size_t)NB * 2;
+constexpr size_t PS_BUF_WORDS = (size_t)MAX_PANEL_WGS * (PS_HDR_WORDS + PS_ROW_WORDS);
+constexpr size_t PS_TOTAL_WORDS = 2 * PS_BUF_WORDS;
+
+template <typename T>
+struct PanelArgs {
+    T* R;
+    int64_t ld;
+    int m, r0, c0, w;
+    int64_t* ipiv;   // global, 1-based entries written at [r0, r0+w)
+    int64_t* info;   // [0] info, [1] error flag
+    u64* scratch;
+    unsigned epoch;  // first tag of this launch (w consecutive tags are used)
+    int G;
+    int* pm_cnt;     // chunk bookkeeping outputs for chunk r0/NB
+    int* pm_dst;
+    int* pm_src;
+};
+
+__device__ __forceinline__ double tabs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float tabs(float x) { return __builtin_fabsf(x); }
+
+template <typename T>
+__device__ __forceinline__ bool better(T ov, unsigned op, T bv, unsigned bp)
+{
+    return ov > bv || (ov == bv && op < bp);
+}
+
+// Turn w sequential interchanges (position base+i <-> piv[i], piv global 0-based) into an equivalent list of row moves
+// new[dst] = old[src].  One wave; rows/content are LDS scratch of 2*NB ints each.
+__device__ void perm_build_wave(const int* piv, int base, int w, int lane, int* rows, int* content, int* out_cnt,
+                                int* out_dst, int* out_src)
+{
+    rows[lane] = base + lane;
+    content[lane] = lane;
+    rows[NB + lane] = -1;
+    content[NB + lane] = NB + lane;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    int nextra = 0;
+    for (int i = 0; i < w; ++i) {
+        const int p = piv[i];
+        int sp;
+        if (p < base + NB) {
+            sp = p - base;
+        } else {
+            const bool hit = (lane < nextra) && (rows[NB + lane] == p);
+            const u64 mask = __ballot(hit);
+            if (mask) {
+                sp = NB + (__ffsll((long long)mask) - 1);
+            } else {
+                sp = NB + nextra;
+                if (lane == 0) rows[sp] = p;
+                ++nextra;
+            }
+        }
+        __threadfence_block();
+        if (lane == 0 && sp != i) {
+            const int t = content[i];
+            content[i] = content[sp];
+            content[sp] = t;
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+    }
+    int total = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int s = half * NB + lane;
+        const bool moved = (half == 0 || lane < nextra) && (content[s] != s);
+        const u64 mask = __ballot(moved);
+        if (moved) {
+            const int off = total + __popcll(mask & ((1ull << lane) - 1ull));
+            out_dst[off] = rows[s];
+            out_src[off] = rows[content[s]];
+        }
+        total += __popcll(mask);
+    }
+    if (lane == 0) *out_cnt = total;
+}
+
+__global__ void __launch_bounds__(64) perm_build_kernel(const int64_t* ipiv, int k0, int k1, int* pm_cnt, int* pm_dst,
+                                                        int* pm_src)
+{
+    __shared__ int s_piv[NB];
+    __shared__ int s_rows[2 * NB];
+    __shared__ int s_content[2 * NB];
+    const int lane = threadIdx.x;
+    const int chunk = k0 / NB + blockIdx.x;
+    const int base = chunk * NB;
+    const int w = min(NB, k1 - base);
+    s_piv[lane] = (lane < w) ? (int)(ipiv[base + lane] - 1) : base + lane;
+    __syncthreads();
+    perm_build_wave(s_piv, base, w, lane, s_rows, s_content, pm_cnt + chunk, pm_dst + (size_t)chunk * 2 * NB,
+                    pm_src + (size_t)chunk * 2 * NB);
+}
+
+int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, int64_t m)
+{
+    (void)m;
+    if (k1 <= k0) return RFLU_OK;
+    const int nchunks = (int)((k1 - k0 + NB - 1) / NB);
+    ProfScope ps(h, RFLU_K_MISC, 0.0);
+    hipLaunchKernelGGL(perm_build_kernel, dim3(nchunks), dim3(64), 0, h->stream, ipiv, (int)k0, (int)k1, h->pm_cnt,
+                       h->pm_dst, h->pm_src);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+// ---- row <-> register staging through an LDS transpose (coalesced 512-byte row segments on the memory side) -------
+template <typename T, int RT>
+__device__ __forceinline__ void load_rows(const T* R, int64_t ld, int row_base, int m, int c0, int w, T (&a)[RT][NB],
+                                          T* tile, int wave, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+#pragma unroll
+        for (int chunk = 0; chunk < 4; ++chunk) {
+            const int rb = row_base + q * PANEL_THREADS + chunk * 64;
+            for (int rr = wave; rr < 64; rr += 4) {
+                const int grow = rb + rr;
+                T v = T(0);
+                if (grow < m && lane < w) v = R[(int64_t)grow * ld + c0 + lane];
+                tile[rr * TILE_LD + lane] = v;
+            }
+            __syncthreads();
+            if (wave == chunk) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) a[q][j] = tile[lane * TILE_LD + j];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T, int RT>
+__device__ __forceinline__ void store_rows(T* R, int64_t ld, int c0, int w, const T (&a)[RT][NB],
+                                           const unsigned (&pos)[RT], T* tile, int* spos, int wave, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+#pragma unroll
+        for (int chunk = 0; chunk < 4; ++chunk) {
+            if (wave == chunk) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) tile[lane * TILE_LD + j] = a[q][j];
+                spos[lane] = (pos[q] == POS_NONE) ? -1 : (int)pos[q];
+            }
+            __syncthreads();
+            for (int rr = wave; rr < 64; rr += 4) {
+                const int p = spos[rr];
+                if (p >= 0 && lane < w) R[(int64_t)p * ld + c0 + lane] = tile[rr * TILE_LD + lane];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// =====================================================================================================================
+// Pivoted leaf panel
+// =====================================================================================================================
+template <typename T>
+struct PivotShared {
+    T* crow;            // [4][NB] per-wave candidate rows
+    T* prow;            // [NB] pivot row of this step
+    T* wval;            // [4]
+    unsigned* wpos;     // [4]
+    unsigned* win;      // [1]
+    int* dead;          // [1]
+    int* piv;           // [NB]
+};
+
+// The cross-workgroup part of a pivot step.  Touches no per-thread row registers, so it is kept out of line (one copy
+// instead of 64 in the unrolled step sequence).  On return sh.win / sh.prow[k..NB) hold the pivot position and row.
+// Returns true when the workgroup must give up (a peer never published: timeout).
+template <typename T>
+__device__ __noinline__ bool pivot_exchange(const PanelArgs<T>& p, const PivotShared<T>& sh, int k, int g, int lane,
+                                            int wave)
+{
+    constexpr int GN = Gran<T>::N;
+    const int G = p.G;
+    const unsigned tag = p.epoch + (unsigned)k;
+    u64* const hdr = p.scratch + (size_t)(k & 1) * PS_BUF_WORDS;
+    u64* const rowrec = hdr + (size_t)MAX_PANEL_WGS * PS_HDR_WORDS;
+
+    // ---- workgroup candidate = best of the 4 waves (every thread computes the same answer) ----
+    T cv = sh.wval[0];
+    unsigned cp = sh.wpos[0];
+    int cw = 0;
+#pragma unroll
+    for (int x = 1; x < 4; ++x) {
+        const T ov = sh.wval[x];
+        const unsigned op = sh.wpos[x];
+        if (better<T>(ov, op, cv, cp)) { cv = ov; cp = op; cw = x; }
+    }
+
+    if (G == 1) {
+        // single workgroup: the candidate is the pivot; no exchange
+        if (wave == 0) {
+            if (lane >= k && lane < NB) sh.prow[lane] = sh.crow[cw * NB + lane];
+            if (lane == 0) *sh.win = cp;
+        }
+        __syncthreads();
+        return false;
+    }
+    // ---- publish (wave 3) ----
+    if (wave == 3) {
+        if (cp != POS_NONE) {
+            if (lane >= k && lane < NB)
+                Gran<T>::store(rowrec + (size_t)g * PS_ROW_WORDS + lane * GN, tag, sh.crow[cw * NB + lane]);
+            if (lane == 0) Gran<T>::store(hdr + (size_t)g * PS_HDR_WORDS + 1, tag, sh.crow[cw * NB + k]);
+        }
+        if (lane == 0) gran_store(hdr + (size_t)g * PS_HDR_WORDS, tag, cp);
+    }
+    // ---- poll all headers, pick the global winner, fetch its row (wave 0) ----
+    if (wave == 0) {
+        bool timed_out = false;
+        T gv = T(-1);
+        unsigned gp = POS_NONE;
+        int gg = 0;
+        for (int x = lane; x < G; x += 64) {
+            const u64* hx = hdr + (size_t)x * PS_HDR_WORDS;
+            int spins = 0;
+            u64 h0;
+            for (;;) {
+                h0 = gran_load(hx);
+                if ((unsigned)(h0 >> 32) == tag) break;
+                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const unsigned xp = (unsigned)h0;
+            if (!timed_out && xp != POS_NONE) {
+                T xv = T(0);
+                spins = 0;
+                while (!Gran<T>::load(hx + 1, tag, xv)) {
+                    if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+                }
+                const T av = tabs(xv);
+                const T key = (av > T(0)) ? av : T(0);
+                if (better<T>(key, xp, gv, gp)) { gv = key; gp = xp; gg = x; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const T ov = __shfl_xor(gv, off);
+            const unsigned op = (unsigned)__shfl_xor((int)gp, off);
+            const int og = __shfl_xor(gg, off);
+            if (better<T>(ov, op, gv, gp)) { gv = ov; gp = op; gg = og; }
+        }
+        if (lane >= k && lane < NB && gp != POS_NONE) {
+            T xv = T(0);
+            int spins = 0;
+            while (!Gran<T>::load(rowrec + (size_t)gg * PS_ROW_WORDS + lane * GN, tag, xv)) {
+                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+            }
+            sh.prow[lane] = xv;
+        }
+        if (lane == 0) *sh.win = gp;
+        if (__any(timed_out)) {
+            if (lane == 0) {
+                __hip_atomic_store((u64*)(p.info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *sh.win = POS_NONE;
+                *sh.dead = 1;
+            }
+        }
+    }
+    __syncthreads();
+    return *sh.dead != 0;
+}
+
+// One pivot step, K a compile-time constant so that every register-array index below is static.
+template <typename T, int RT, int K>
+__device__ __forceinline__ void pivot_step(const PanelArgs<T>& p, const PivotShared<T>& sh, T (&a)[RT][NB],
+                                           unsigned (&pos)[RT], bool (&act)[RT], bool& dead, int g, int tid, int lane,
+                                           int wave)
+{
+    if (K >= p.w || dead) return;
+
+    // ---- local candidate: key = |a| if > 0 (NaN and 0 -> 0), ties -> lowest position ----
+    T bv = T(-1);
+    unsigned bp = POS_NONE;
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        if (act[q]) {
+            const T v = tabs(a[q][K]);
+            const T key = (v > T(0)) ? v : T(0);
+            if (better<T>(key, pos[q], bv, bp)) { bv = key; bp = pos[q]; }
+        }
+    }
+    T wv = bv;
+    unsigned wp = bp;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const T ov = __shfl_xor(wv, off);
+        const unsigned op = (unsigned)__shfl_xor((int)wp, off);
+        if (better<T>(ov, op, wv, wp)) { wv = ov; wp = op; }
+    }
+    // the wave's winning row is dumped to LDS by its owner (columns K..NB-1)
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        if (act[q] && pos[q] == wp) {
+#pragma unroll
+            for (int j = K; j < NB; ++j) sh.crow[wave * NB + j] = a[q][j];
+        }
+    }
+    if (lane == 0) { sh.wval[wave] = wv; sh.wpos[wave] = wp; }
+    __syncthreads();
+
+    dead = pivot_exchange<T>(p, sh, K, g, lane, wave);
+    const unsigned win_pos = *sh.win;
+
+    // ---- bookkeeping + rank-1 update -----------------------------------------------------------------------------
+    if (win_pos != POS_NONE) {
+        const T piv = sh.prow[K];
+        const bool has = (piv != T(0));
+        const unsigned kpos = (unsigned)(p.r0 + K);
+        if (g == 0 && tid == 0) {
+            p.ipiv[p.r0 + K] = (int64_t)win_pos + 1;
+            sh.piv[K] = (int)win_pos;
+            if (!has && p.info[0] == 0) p.info[0] = (int64_t)p.r0 + K + 1;
+        }
+        const T inv = has ? T(1) / piv : T(1);
+#pragma unroll
+        for (int q = 0; q < RT; ++q) {
+            if (act[q]) {
+                if (pos[q] == win_pos) {
+                    act[q] = false;  // pivot row: final position r0+K, no further updates
+                    pos[q] = kpos;
+                } else {
+                    if (pos[q] == kpos) pos[q] = win_pos;  // displaced row takes the pivot's old position
+                    T l = a[q][K];
+                    if (has) l *= inv;
+                    a[q][K] = l;
+#pragma unroll
+                    for (int j = K + 1; j < NB; ++j) a[q][j] -= l * sh.prow[j];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int RT, int K0, int K1>
+struct PivotSteps {
+    static __device__ __forceinline__ void run(const PanelArgs<T>& p, const PivotShared<T>& sh, T (&a)[RT][NB],
+                                               unsigned (&pos)[RT], bool (&act)[RT], bool& dead, int g, int tid,
+                                               int lane, int wave)
+    {
+        if constexpr (K0 < K1) {
+            pivot_step<T, RT, K0>(p, sh, a, pos, act, dead, g, tid, lane, wave);
+            PivotSteps<T, RT, K0 + 1, K1>::run(p, sh, a, pos, act, dead, g, tid, lane, wave);
+        }
+    }
+};
+
+template <typename T, int RT>
+__global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_kernel(PanelArgs<T> p)
+{
+    __shared__ T s_tile[64 * TILE_LD];
+    __shared__ T s_crow[4 * NB];
+    __shared__ T s_prow[NB];
+    __shared__ T s_wval[4];
+    __shared__ unsigned s_wpos[4];
+    __shared__ unsigned s_win;
+    __shared__ int s_dead;
+    __shared__ int s_piv[NB];
+    __shared__ int s_spos[64];
+    __shared__ int s_rows[2 * NB];
+    __shared__ int s_content[2 * NB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int w = p.w;
+    const int row_base = p.r0 + g * (PANEL_THREADS * RT);
+
+    T a[RT][NB];
+    unsigned pos[RT];   // current row position of this thread's row; POS_NONE for rows beyond m
+    bool act[RT];       // still a pivot candidate (not yet chosen, inside the matrix)
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        const int row = row_base + q * PANEL_THREADS + tid;
+        act[q] = row < p.m;
+        pos[q] = act[q] ? (unsigned)row : POS_NONE;
+    }
+    if (tid == 0) s_dead = 0;
+    load_rows<T, RT>(p.R, p.ld, row_base, p.m, p.c0, w, a, s_tile, wave, lane);
+
+    PivotShared<T> sh;
+    sh.crow = s_crow; sh.prow = s_prow; sh.wval = s_wval; sh.wpos = s_wpos; sh.win = &s_win; sh.dead = &s_dead;
+    sh.piv = s_piv;
+    bool dead = false;  // set (workgroup-uniformly) after a timeout: skip the remaining steps quickly
+    PivotSteps<T, RT, 0, NB>::run(p, sh, a, pos, act, dead, g, tid, lane, wave);
+
+    store_rows<T, RT>(p.R, p.ld, p.c0, w, a, pos, s_tile, s_spos, wave, lane);
+
+    if (g == 0 && wave == 3) {
+        __threadfence_block();
+        const int chunk = p.r0 / NB;
+        perm_build_wave(s_piv, p.r0, w, lane, s_rows, s_content, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
+                        p.pm_src + (size_t)chunk * 2 * NB);
+    }
+}
+
+// =====================================================================================================================
+// NoPivot leaf panel (Val(false) / NoPivot()): no exchange between workgroups.
+//   kernel 1 (one workgroup): unpivoted LU of the w x w top block, in place.
+//   kernel 2 (G workgroups) : every row below solves  l_i * U11 = a_i  against the factored top block held in LDS.
+// =====================================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(PANEL_THREADS) panel_nopivot_top_kernel(PanelArgs<T> p)
+{
+    __shared__ T s_U[NB * TILE_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = p.w;
+    for (int rr = wave; rr < NB; rr += 4) {
+        T v = T(0);
+        if (rr < w && lane < w) v = p.R[(int64_t)(p.r0 + rr) * p.ld + p.c0 + lane];
+        s_U[rr * TILE_LD + lane] = v;
+    }
+    __syncthreads();
+    // thread (i = tid>>2, part = tid&3) updates columns j = k+1+part, +4, ... of row i
+    const int i = tid >> 2, part = tid & 3;
+    for (int k = 0; k < w; ++k) {
+        const T piv = s_U[k * TILE_LD + k];
+        const bool has = (piv != T(0));
+        const T inv = has ? T(1) / piv : T(1);
+        T l = T(0);
+        if (i > k && i < w) {
+            l = s_U[i * TILE_LD + k];
+            if (has) l *= inv;
+        }
+        __syncthreads();
+        if (i > k && i < w) {
+            if (part == 0) s_U[i * TILE_LD + k] = l;
+            for (int j = k + 1 + part; j < w; j += 4) s_U[i * TILE_LD + j] -= l * s_U[k * TILE_LD + j];
+        }
+        if (tid == 0 && !has && p.info[0] == 0) p.info[0] = (int64_t)p.r0 + k + 1;
+        __syncthreads();
+    }
+    for (int rr = wave; rr < w; rr += 4)
+        if (lane < w) p.R[(int64_t)(p.r0 + rr) * p.ld + p.c0 + lane] = s_U[rr * TILE_LD + lane];
+}
+
+template <typename T, int RT, int K0, int K1>
+struct NoPivotSteps {
+    static __device__ __forceinline__ void run(int w, const T* s_U, T (&a)[RT][NB])
+    {
+        if constexpr (K0 < K1) {
+            if (K0 < w) {
+                const T piv = s_U[K0 * TILE_LD + K0];
+                const bool has = (piv != T(0));
+                const T inv = has ? T(1) / piv : T(1);
+#pragma unroll
+                for (int q = 0; q < RT; ++q) {
+                    T l = a[q][K0];
+                    if (has) l *= inv;
+                    a[q][K0] = l;
+#pragma unroll
+                    for (int j = K0 + 1; j < NB; ++j) a[q][j] -= l * s_U[K0 * TILE_LD + j];
+                }
+            }
+            NoPivotSteps<T, RT, K0 + 1, K1>::run(w, s_U, a);
+        }
+    }
+};
+
+template <typename T, int RT>
+__global__ void __launch_bounds__(PANEL_THREADS) panel_nopivot_rows_kernel(PanelArgs<T> p)
+{
+    __shared__ T s_tile[64 * TILE_LD];
+    __shared__ T s_U[NB * TILE_LD];  // factored top block L11\U11 (only U11 is used)
+    __shared__ int s_spos[64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int w = p.w;
+    const int row_base = p.r0 + w + g * (PANEL_THREADS * RT);
+
+    for (int rr = wave; rr < NB; rr += 4) {
+        T v = T(0);
+        if (rr < w && lane < w) v = p.R[(int64_t)(p.r0 + rr) * p.ld + p.c0 + lane];
+        s_U[rr * TILE_LD + lane] = v;
+    }
+    T a[RT][NB];
+    unsigned pos[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        const int row = row_base + q * PANEL_THREADS + tid;
+        pos[q] = (row < p.m) ? (unsigned)row : POS_NONE;
+    }
+    load_rows<T, RT>(p.R, p.ld, row_base, p.m, p.c0, w, a, s_tile, wave, lane);  // contains __syncthreads
+    NoPivotSteps<T, RT, 0, NB>::run(w, s_U, a);
+    store_rows<T, RT>(p.R, p.ld, p.c0, w, a, pos, s_tile, s_spos, wave, lane);
+}
+
+template <typename T>
+int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0, int64_t w, int64_t* ipiv, int pivot)
+{
+    if (w <= 0) return RFLU_OK;
+    if (w > NB || r0 % NB != 0 || m - r0 < w) {
+        set_error("launch_panel: unsupported geometry m=%lld r0=%lld w=%lld", (long long)m, (long long)r0, (long long)w);
+        return RFLU_ERR_ARG;
+    }
+    const int64_t rows = m - r0;
+    int rt = 1;
+    while ((rows + (int64_t)PANEL_THREADS * rt - 1) / ((int64_t)PANEL_THREADS * rt) > MAX_PANEL_WGS) rt *= 2;
+    if (rt > 1) {
+        set_error("launch_panel: %lld rows exceed the supported 65536", (long long)rows);
+        return RFLU_ERR_ARG;
+    }
+    PanelArgs<T> p;
+    p.R = R; p.ld = ld; p.m = (int)m; p.r0 = (int)r0; p.c0 = (int)c0; p.w = (int)w;
+    p.ipiv = ipiv; p.info = h->info_dev; p.scratch = h->pscratch;
+    p.G = (int)((rows + (int64_t)PANEL_THREADS * rt - 1) / ((int64_t)PANEL_THREADS * rt));
+    p.pm_cnt = h->pm_cnt; p.pm_dst = h->pm_dst; p.pm_src = h->pm_src;
+    p.epoch = h->epoch;
+    h->epoch += (unsigned)NB;
+    if (h->epoch > 0xfffff000u) {  // tag wrap: wipe the records and restart the epoch counter
+        RFLU_HIP(hipMemsetAsync(h->pscratch, 0, h->pscratch_bytes, h->stream));
+        h->epoch = 1;
+        p.epoch = h->epoch;
+        h->epoch += (unsigned)NB;
+    }
+    ProfScope ps(h, RFLU_K_PANEL, (double)rows * (double)w * (double)w);
+    if (pivot) {
+        hipLaunchKernelGGL((panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
+    } else {
+        hipLaunchKernelGGL((panel_nopivot_top_kernel<T>), dim3(1), dim3(PANEL_THREADS), 0, h->stream, p);
+        const int64_t below = rows - w;
+        if (below > 0) {
+            const int gb = (int)((below + (int64_t)PANEL_THREADS * rt - 1) / ((int64_t)PANEL_THREADS * rt));
+            hipLaunchKernelGGL((panel_nopivot_rows_kernel<T, 1>), dim3(gb), dim3(PANEL_THREADS), 0, h->stream, p);
+        }
+    }
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
+template int launch_panel<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
+
+size_t panel_scratch_bytes() { return PS_TOTAL_WORDS * sizeof(u64); }
+
+}  // namespace rflu

@@ -1,0 +1,125 @@
+// rflu_internal.hpp -- shared declarations of librflu.so (MI355X / gfx950 only; no other targets, no CPU fallback).
+//
+// Internal data layout ("R layout"): the matrix lives ROW-major in HBM, element (i,j) at R[i*ld + j], ld a multiple
+// of 16 elements so every row starts on a 128-byte line.  Why: the row interchanges of partial pivoting
+// (apply_permutation!, /root/reference/src/lu.jl:164-188) then move contiguous row segments (perfectly coalesced,
+// 32 B of traffic per pivot per column, no cache-line amplification), and a panel row is one contiguous 512-byte run.
+// The column-major boundary (rflu_getrf_*_dev) converts with two tiled transposes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rflu.h"
+
+namespace rflu {
+
+constexpr int NB = 64;            // leaf panel width == pivot chunk size (columns per cooperative panel kernel)
+constexpr int PANEL_THREADS = 256;
+constexpr int MAX_PANEL_WGS = 256;  // one workgroup per CU at most: all must be co-resident (they spin on each other)
+
+// ---- error plumbing -------------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define RFLU_HIP(call)                                                                         \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            ::rflu::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return RFLU_ERR_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+#define RFLU_TRY(expr)            \
+    do {                          \
+        int s__ = (expr);         \
+        if (s__ != RFLU_OK) return s__; \
+    } while (0)
+
+// ---- per-kernel-class timers ------------------------------------------------------------------------------------------
+struct ProfSlot {
+    double ms = 0.0;
+    int64_t launches = 0;
+    double work = 0.0;
+};
+
+struct Handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int last_path = RFLU_PATH_NONE;
+    int num_cus = 256;
+
+    // workspaces (grown on demand, kept for reuse across calls -- LinearSolve-style cache reuse)
+    void* work = nullptr;        // row-major copy of the matrix for the column-major entry points
+    size_t work_bytes = 0;
+    int64_t* ipiv_dev = nullptr; // device pivots for the host entry points
+    size_t ipiv_cap = 0;
+    void* hostA_dev = nullptr;   // device copy of the host matrix (host entry points)
+    size_t hostA_bytes = 0;
+
+    // pivot bookkeeping: for every chunk of NB pivots the list of (dst,src) row moves equivalent to its interchanges
+    int* pm_cnt = nullptr;
+    int* pm_dst = nullptr;
+    int* pm_src = nullptr;
+    int64_t pm_chunks = 0;
+
+    // cooperative panel scratch: double-buffered granule records + status words
+    unsigned long long* pscratch = nullptr;
+    size_t pscratch_bytes = 0;
+    unsigned epoch = 1;          // next unused granule tag
+    int64_t* info_dev = nullptr; // [0] = info, [1] = panel error flag
+    int64_t* info_pinned = nullptr;
+
+    // timers
+    bool prof = false;
+    ProfSlot slots[RFLU_K_COUNT];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct ProfScope {
+    Handle* h;
+    int k;
+    double work;
+    bool on;
+    ProfScope(Handle* h_, int k_, double work_) : h(h_), k(k_), work(work_), on(h_->prof) {
+        if (on) (void)hipEventRecord(h->ev0, h->stream);
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(h->ev1, h->stream);
+            (void)hipEventSynchronize(h->ev1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+            h->slots[k].ms += ms;
+            h->slots[k].launches += 1;
+            h->slots[k].work += work;
+        }
+    }
+};
+
+int ensure_bookkeeping(Handle* h, int64_t rows);
+
+// ---- kernel launchers (each returns an rflu_status); all pointers are device pointers in R layout -----------------------
+template <typename T>
+int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C,
+                int64_t ldc);
+template <typename T>
+int launch_trsm_base(Handle* h, int64_t nb, int64_t nrhs, const T* L, int64_t ldl, T* B, int64_t ldb);
+template <typename T>
+int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t chunk0, int64_t chunk1);
+// apply chunks [chunk0, chunk1) to two column ranges at once: [c0, c0+ncolsA) and [c1, c1+ncolsB)
+template <typename T>
+int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t chunk0,
+                  int64_t chunk1);
+// fold the interchanges ipiv[k0..k1) (k0 a multiple of NB) into per-chunk row-move lists
+int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, int64_t m);
+size_t panel_scratch_bytes();
+template <typename T>
+int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0, int64_t w, int64_t* ipiv, int pivot);
+template <typename T>
+int launch_transpose(Handle* h, int64_t rows_out, int64_t cols_out, const T* in, int64_t ld_in, T* out, int64_t ld_out);
+template <typename T>
+int launch_fill_uniform(Handle* h, T* A, int64_t m, int64_t n, int64_t ld, int row_major, uint64_t seed,
+                        int64_t M_global, int64_t i0, int64_t j0, double diag_add);
+int launch_iota_ipiv(Handle* h, int64_t* ipiv, int64_t k0, int64_t n);
+
+}  // namespace rflu

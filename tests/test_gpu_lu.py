@@ -1,0 +1,175 @@
+"""-m gpu: parity of the HIP path with the CPU oracle through the reference-shaped API (lu / lu_), mirroring
+/root/reference/test/runtests.jl.  Bars: ipiv and info bit-exact (integer work); factors and residual within the
+reference's own Float64/Float32 tolerance  max|L*U - A[p,:]| < 20*s*eps  (runtests.jl:19-20), written in each test."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+
+import oracle as O
+import recursivefactorization.jl_amd as rf
+from gpu_util import to_dev_cm
+from helpers import REF_SIZES, rand_matrix, wilkinson
+
+pytestmark = pytest.mark.gpu
+
+
+def tol_E(A):
+    return 20 * A.shape[0] * np.finfo(A.dtype).eps
+
+
+def check_against_oracle(A, F, pivot=True, factor_tol_mult=50):
+    Fo, ipo, infoo = O.lu(A, pivot=pivot)
+    lu_host = F.factors.cpu().numpy() if hasattr(F.factors, "cpu") else np.asarray(F.factors)
+    ip = np.asarray(F.ipiv.cpu().numpy() if hasattr(F.ipiv, "cpu") else F.ipiv)
+    assert abs(F.info) == infoo
+    assert np.array_equal(ip, ipo), "ipiv must be bit-exact"
+    if infoo == 0:
+        mx, fro = O.residual(A, lu_host, ip)
+        bound = tol_E(A) if pivot else 10 * np.sqrt(tol_E(A)) * max(1.0, float(np.max(np.abs(Fo))))
+        assert mx < bound
+        scale = max(1.0, float(np.max(np.abs(Fo))))
+        assert np.max(np.abs(lu_host - Fo)) < factor_tol_mult * tol_E(A) * scale
+    return lu_host, ip
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("s", REF_SIZES)
+def test_lu_reference_shapes_pivoted(dtype, s):
+    # runtests.jl:33-68, pivot = Val(true) / RowMaximum(), square and fat, host boundary (numpy) and device boundary
+    for m in (s, s + 2):
+        A = rand_matrix(s, m, seed=1000 * s + m, dtype=dtype)
+        F = rf.lu(A, rf.RowMaximum() if s % 2 else rf.Val(True), check=False)
+        assert rf.last_path() == "hip-recursive"
+        check_against_oracle(A, F)
+        Fd = rf.lu_(to_dev_cm(A), None, True, check=False)
+        check_against_oracle(A, Fd)
+        # singular: zero a column, check=false, info must match (runtests.jl:59-64)
+        i = (7 * s + m) % s
+        A2 = A.copy()
+        A2[:, i] = 0
+        F2 = rf.lu(A2, True, check=False)
+        assert F2.info == i + 1
+        assert np.array_equal(F2.ipiv, O.lu(A2)[1])
+        with pytest.raises(rf.SingularException):
+            rf.lu(A2, True)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("s", [1, 2, 7, 10, 50, 130, 300])
+def test_lu_nopivot(dtype, s):
+    # runtests.jl:33-68 with pivot = Val(false)/NoPivot(): bound 10*sqrt(E); NotIPIV result; identity fill of a user ipiv
+    for m in (s, s + 2):
+        A = (rand_matrix(s, m, seed=2000 * s + m, dtype=dtype) + dtype(10) * np.eye(s, m, dtype=dtype)).astype(dtype, order="F")
+        F = rf.lu(A, rf.NoPivot(), check=False)
+        assert isinstance(F.ipiv, rf.NotIPIV) and len(F.ipiv) == s
+        check_against_oracle(A, rf.LU(F.factors, np.arange(1, s + 1), F.info), pivot=False)
+    # runtests.jl:70-84: poisoned user ipiv comes back == 1:n
+    n = 30
+    A = (rand_matrix(n, n, seed=3, dtype=dtype) + dtype(10) * np.eye(n, dtype=dtype)).astype(dtype, order="F")
+    ipiv = np.full(n, np.iinfo(np.int64).max - 7, dtype=np.int64)
+    F = rf.lu_(A.copy(order="F"), ipiv, rf.Val(False), rf.Val(False))
+    assert F.ipiv is ipiv and np.array_equal(ipiv, np.arange(1, n + 1))
+    b = rand_matrix(n, 1, seed=4, dtype=dtype)[:, 0]
+    x = sla.lu_solve((F.factors, ipiv - 1), b)
+    assert np.linalg.norm(A.astype(np.float64) @ x - b) < 1000 * n * np.finfo(dtype).eps
+
+
+def test_nopivot_zero_pivot_sign_convention():
+    A = np.asfortranarray(np.triu(rand_matrix(100, 100, seed=6)) + 10 * np.eye(100))
+    A[70, 70] = 0.0
+    F = rf.lu(A, rf.NoPivot(), check=False)
+    assert F.info == (-71 if rf.NOPIVOT_NEGATIVE_INFO else 71)  # src/lu.jl:249-254, 323-326
+    with pytest.raises(rf.SingularException):
+        rf.lu(A, rf.NoPivot())
+
+
+@pytest.mark.parametrize("n,dtype", [(512, np.float64), (1000, np.float64), (2048, np.float64), (1000, np.float32),
+                                     (2048, np.float32)])
+def test_lu_medium_sizes_vs_oracle(n, dtype):
+    A = rand_matrix(n, n, seed=12, dtype=dtype)
+    F = rf.lu_(to_dev_cm(A), None, True, check=False)
+    check_against_oracle(A, F)
+
+
+@pytest.mark.parametrize("shape", [(400, 130), (1000, 64), (130, 400), (64, 1000), (777, 333)])
+def test_lu_tall_and_fat(shape):
+    A = rand_matrix(shape[0], shape[1], seed=77)
+    F = rf.lu(A, True, check=False)
+    check_against_oracle(A, F)
+
+
+@pytest.mark.parametrize("blocksize", [64, 128, 256])
+def test_blocked_right_looking_variant_gives_same_pivots(blocksize):
+    A = rand_matrix(1000, 1000, seed=10)
+    F = rf.lu(A, True, check=False, blocksize=blocksize)
+    assert rf.last_path() == "hip-blocked"
+    check_against_oracle(A, F)
+
+
+def test_row_major_device_entry():
+    A = rand_matrix(700, 700, seed=21)
+    d = torch.from_numpy(np.ascontiguousarray(A)).to("cuda:0")
+    F = rf.lu_(d, None, True, check=False)
+    check_against_oracle(A, F)
+
+
+def test_wilkinson_ties_nan():
+    # runtests.jl:130-140 generator: every search is an exact tie -> lowest index -> identity pivots, growth 2^(k-1)
+    for n in (50, 130, 300):
+        A = wilkinson(n)
+        F = rf.lu(A, True, check=False)
+        assert F.info == 0 and np.array_equal(F.ipiv, np.arange(1, n + 1))
+        assert np.array_equal(np.asarray(F.factors)[:, -1], 2.0 ** np.arange(n))
+    # small-integer matrix with many exact ties
+    T = np.asfortranarray(np.floor(rand_matrix(300, 300, seed=413) * 4) - 1.5)
+    F = rf.lu(T, True, check=False)
+    assert np.array_equal(F.ipiv, O.lu(T)[1])
+    # NaN never wins the argmax (src/lu.jl:298-304)
+    N = rand_matrix(130, 130, seed=512)
+    N[5, 0] = np.nan
+    F = rf.lu(N, True, check=False)
+    assert np.array_equal(F.ipiv, O.lu(N)[1])
+
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_hip_path_reproduces_golden_fixtures(path):
+    from golden.make_golden import build_input
+
+    g = np.load(path, allow_pickle=False)
+    A = build_input(g)
+    pivot = bool(g["pivot"])
+    F = rf.lu(A, pivot, check=False)
+    assert abs(F.info) == int(g["info"])
+    ip = np.asarray(F.ipiv)
+    assert np.array_equal(ip, g["ipiv"])
+    ok = np.isfinite(g["lu_sample"])
+    got = np.asarray(F.factors).ravel(order="F")[g["sample_idx"]]
+    tol = 64 * np.finfo(A.dtype).eps * max(A.shape) * max(1.0, float(np.max(np.abs(g["lu_sample"][ok]))))
+    assert np.allclose(got[ok], g["lu_sample"][ok], atol=tol, rtol=0)
+
+
+def test_large_properties_on_device():
+    # BASELINE config sizes: size-independent properties computed on the GPU with torch (an independent checker):
+    # ||PA - LU||_F / ||A||_F < 1e-12 and ipiv == LAPACK getrf (same comparator as the reference's tests)
+    n = 4096
+    A = rand_matrix(n, n, seed=12)
+    dA = to_dev_cm(A)
+    F = rf.lu_(dA, None, True, check=False)
+    ip = F.ipiv.cpu().numpy()
+    _, lpiv, linfo = sla.lapack.dgetrf(A)
+    assert F.info == linfo == 0
+    assert np.array_equal(ip, lpiv.astype(np.int64) + 1)
+    LUm = F.factors
+    L = torch.tril(LUm, -1) + torch.eye(n, dtype=LUm.dtype, device=LUm.device)
+    U = torch.triu(LUm)
+    perm = torch.from_numpy(O.oracle.perm_from_ipiv(ip, n)).to(LUm.device)
+    PA = torch.from_numpy(A).to(LUm.device)[perm]
+    res = (torch.linalg.norm(L @ U - PA) / torch.linalg.norm(PA)).item()
+    assert res < 1e-12, res

@@ -68,6 +68,13 @@ def load() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build the HIP library first "
                 "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback."
             )
+        # One HIP/HSA runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64.  If librflu were
+        # dlopen'ed first it would pull /opt/rocm's copies and the second HSA runtime loaded by torch finds no device.
+        # Importing torch first lets librflu's NEEDED libamdhip64.so.7 resolve to the already-loaded one.
+        try:
+            import torch  # noqa: F401  (device-memory/stream plumbing only)
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(lib, name)

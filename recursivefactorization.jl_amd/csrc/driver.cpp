@@ -260,7 +260,9 @@ int rflu_create(rflu_handle_t* handle, int device)
     if (!h) { set_error("out of host memory"); return RFLU_ERR_ARG; }
     h->device = device;
     h->num_cus = prop.multiProcessorCount;
-    RFLU_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    // a BLOCKING stream: it orders itself against the legacy default stream, so buffers produced by a framework on
+    // stream 0 (PyTorch's default) need no extra synchronisation before/after a call
+    RFLU_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault));
     h->stream = h->own_stream;
     RFLU_HIP(hipMalloc((void**)&h->info_dev, 2 * sizeof(int64_t)));
     RFLU_HIP(hipHostMalloc((void**)&h->info_pinned, 2 * sizeof(int64_t)));
@@ -400,6 +402,16 @@ int rflu_last_path(rflu_handle_t handle) { return handle ? H(handle)->last_path 
 
 DEFINE_TYPED(f64, double)
 DEFINE_TYPED(f32, float)
+
+/* experiment hook (not in rflu.h): copy the RFLU_PANEL_TRACE clock stamps of the last panel launch to the host */
+int rflu_debug_panel_trace(rflu_handle_t handle, long long* out512)
+{
+    CHECK_HANDLE(handle);
+    Handle* h = H(handle);
+    RFLU_HIP(hipStreamSynchronize(h->stream));
+    RFLU_HIP(hipMemcpy(out512, (char*)h->pscratch + panel_trace_offset_bytes(), 8 * NB * sizeof(long long), hipMemcpyDeviceToHost));
+    return RFLU_OK;
+}
 
 int rflu_profile_enable(rflu_handle_t handle, int enable)
 {

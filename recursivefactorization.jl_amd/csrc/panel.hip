@@ -6,7 +6,7 @@
 // reciprocal-multiply scaling (src/lu.jl:317-320), zero pivot -> record info once and keep updating (:321-334).
 //
 // MI355X design -- a latency problem, not a flop problem (w pivot steps, each a reduction over the whole column):
-//   * G = ceil(rows/256/RT) workgroups, all co-resident, one thread per matrix row, the row's w <= 64 entries live in
+//   * G = ceil(rows/512/RT) workgroups of 512 threads, all co-resident, one thread per matrix row, the row's w <= 64 entries live in
 //     REGISTERS for the whole kernel (fully unrolled column loop => static register indices).  The rank-1 updates
 //     therefore cost ~(w-k) FMAs per thread per step and no memory traffic at all.
 //   * rows never move: every thread tracks the current row POSITION of its row; an interchange just renames two
@@ -32,6 +32,7 @@ typedef unsigned long long u64;
 constexpr unsigned POS_NONE = 0x7fffffffu;
 constexpr int SPIN_LIMIT = 1 << 20;
 constexpr int TILE_LD = NB + 1;
+constexpr int PANEL_WAVES = PANEL_THREADS / 64;
 
 __device__ __forceinline__ void gran_store(u64* p, unsigned tag, unsigned v)
 {
@@ -76,6 +77,14 @@ constexpr size_t PS_HDR_WORDS = 4;
 constexpr size_t PS_ROW_WORDS = (size_t)NB * 2;
 constexpr size_t PS_BUF_WORDS = (size_t)MAX_PANEL_WGS * (PS_HDR_WORDS + PS_ROW_WORDS);
 constexpr size_t PS_TOTAL_WORDS = 2 * PS_BUF_WORDS;
+
+// Optional step tracing (compile with -DRFLU_PANEL_TRACE; experiment builds only): thread 0 of workgroup 0 stores
+// clock64() stamps into the panel scratch area past the granule records.
+#ifdef RFLU_PANEL_TRACE
+#define RFLU_STAMP(scratch, k, i, g, tid) do { if ((g) == 0 && (tid) == 0) ((long long*)((scratch) + PS_TOTAL_WORDS))[(k) * 8 + (i)] = clock64(); } while (0)
+#else
+#define RFLU_STAMP(scratch, k, i, g, tid) do { } while (0)
+#endif
 
 template <typename T>
 struct PanelArgs {
@@ -190,9 +199,9 @@ __device__ __forceinline__ void load_rows(const T* R, int64_t ld, int row_base, 
 #pragma unroll
     for (int q = 0; q < RT; ++q) {
 #pragma unroll
-        for (int chunk = 0; chunk < 4; ++chunk) {
+        for (int chunk = 0; chunk < PANEL_WAVES; ++chunk) {
             const int rb = row_base + q * PANEL_THREADS + chunk * 64;
-            for (int rr = wave; rr < 64; rr += 4) {
+            for (int rr = wave; rr < 64; rr += PANEL_WAVES) {
                 const int grow = rb + rr;
                 T v = T(0);
                 if (grow < m && lane < w) v = R[(int64_t)grow * ld + c0 + lane];
@@ -215,14 +224,14 @@ __device__ __forceinline__ void store_rows(T* R, int64_t ld, int c0, int w, cons
 #pragma unroll
     for (int q = 0; q < RT; ++q) {
 #pragma unroll
-        for (int chunk = 0; chunk < 4; ++chunk) {
+        for (int chunk = 0; chunk < PANEL_WAVES; ++chunk) {
             if (wave == chunk) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) tile[lane * TILE_LD + j] = a[q][j];
                 spos[lane] = (pos[q] == POS_NONE) ? -1 : (int)pos[q];
             }
             __syncthreads();
-            for (int rr = wave; rr < 64; rr += 4) {
+            for (int rr = wave; rr < 64; rr += PANEL_WAVES) {
                 const int p = spos[rr];
                 if (p >= 0 && lane < w) R[(int64_t)p * ld + c0 + lane] = tile[rr * TILE_LD + lane];
             }
@@ -234,60 +243,130 @@ __device__ __forceinline__ void store_rows(T* R, int64_t ld, int c0, int w, cons
 // =====================================================================================================================
 // Pivoted leaf panel
 // =====================================================================================================================
+// ---- all LDS state of the pivoted kernel in ONE object (passed around as a single LDS pointer) ----------------------
 template <typename T>
-struct PivotShared {
-    T* crow;            // [4][NB] per-wave candidate rows
-    T* prow;            // [NB] pivot row of this step
-    T* wval;            // [4]
-    unsigned* wpos;     // [4]
-    unsigned* win;      // [1]
-    int* dead;          // [1]
-    int* piv;           // [NB]
+struct PivotLds {
+    T tile[64 * TILE_LD];   // row <-> register staging
+    T crow[PANEL_WAVES * NB];  // per-wave candidate rows
+    T prow[NB];             // pivot row of this step (columns k..NB-1 valid)
+    T wval[PANEL_WAVES];
+    unsigned wpos[PANEL_WAVES];
+    unsigned win;
+    int dead;
+    int piv[NB];
+    int spos[64];
+    int rows[2 * NB];
+    int content[2 * NB];
 };
 
-// The cross-workgroup part of a pivot step.  Touches no per-thread row registers, so it is kept out of line (one copy
-// instead of 64 in the unrolled step sequence).  On return sh.win / sh.prow[k..NB) hold the pivot position and row.
-// Returns true when the workgroup must give up (a peer never published: timeout).
+// ---- wave-wide argmax of (key, pos): DPP butterflies inside each row of 16 lanes, then 4 row results via readlane ----
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_val(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = dpp_u32<CTRL>((unsigned)b), hi = dpp_u32<CTRL>((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_val(float v)
+{
+    return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v)));
+}
+__device__ __forceinline__ double readlane_val(double v, int l)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ float readlane_val(float v, int l)
+{
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
+
+__device__ __forceinline__ double tmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float tmax(float a, float b) { return __builtin_fmaxf(a, b); }
+
+// max of a non-negative, NaN-free key over the wave; every lane gets the result
 template <typename T>
-__device__ __noinline__ bool pivot_exchange(const PanelArgs<T>& p, const PivotShared<T>& sh, int k, int g, int lane,
-                                            int wave)
+__device__ __forceinline__ T wave_max(T v)
+{
+    v = tmax(v, dpp_val<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = tmax(v, dpp_val<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = tmax(v, dpp_val<0x141>(v));  // row_half_mirror
+    v = tmax(v, dpp_val<0x140>(v));  // row_mirror  -> every lane of a 16-lane row holds the row max
+    const T r0 = readlane_val(v, 0), r1 = readlane_val(v, 16), r2 = readlane_val(v, 32), r3 = readlane_val(v, 48);
+    return tmax(tmax(r0, r1), tmax(r2, r3));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x141>(v));
+    v = min(v, dpp_u32<0x140>(v));
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
+// Wave-wide argmax of (key desc, pos asc): two cheap passes (v_max on the key, then v_min on the positions of the lanes
+// that hold the maximum) instead of a compare-select butterfly on (key,pos) pairs.  Keys are >= 0 and never NaN.
+template <typename T>
+__device__ __forceinline__ void wave_argmax(T& v, unsigned& p)
+{
+    const T m = wave_max<T>(v);
+    const unsigned cand = (v == m) ? p : POS_NONE;
+    p = wave_min_u32(cand);
+    v = m;
+}
+
+// The cross-workgroup part of a pivot step.  Touches no per-thread row registers, so it is kept out of line (one copy
+// instead of 64 in the unrolled step sequence); every argument travels by value in registers.
+// On return sh->win / sh->prow[k..NB) hold the pivot position and row.  Returns true when the workgroup must give up.
+template <typename T>
+__device__ __noinline__ bool pivot_exchange(PivotLds<T>* sh, u64* scratch, int64_t* info, unsigned epoch, int G, int k,
+                                            int g, int lane, int wave)
 {
     constexpr int GN = Gran<T>::N;
-    const int G = p.G;
-    const unsigned tag = p.epoch + (unsigned)k;
-    u64* const hdr = p.scratch + (size_t)(k & 1) * PS_BUF_WORDS;
+    const unsigned tag = epoch + (unsigned)k;
+    u64* const hdr = scratch + (size_t)(k & 1) * PS_BUF_WORDS;
     u64* const rowrec = hdr + (size_t)MAX_PANEL_WGS * PS_HDR_WORDS;
 
-    // ---- workgroup candidate = best of the 4 waves (every thread computes the same answer) ----
-    T cv = sh.wval[0];
-    unsigned cp = sh.wpos[0];
+    // ---- workgroup candidate = best of the waves (every thread computes the same answer) ----
+    T cv = sh->wval[0];
+    unsigned cp = sh->wpos[0];
     int cw = 0;
 #pragma unroll
-    for (int x = 1; x < 4; ++x) {
-        const T ov = sh.wval[x];
-        const unsigned op = sh.wpos[x];
+    for (int x = 1; x < PANEL_WAVES; ++x) {
+        const T ov = sh->wval[x];
+        const unsigned op = sh->wpos[x];
         if (better<T>(ov, op, cv, cp)) { cv = ov; cp = op; cw = x; }
     }
 
     if (G == 1) {
         // single workgroup: the candidate is the pivot; no exchange
         if (wave == 0) {
-            if (lane >= k && lane < NB) sh.prow[lane] = sh.crow[cw * NB + lane];
-            if (lane == 0) *sh.win = cp;
+            if (lane >= k && lane < NB) sh->prow[lane] = sh->crow[cw * NB + lane];
+            if (lane == 0) sh->win = cp;
         }
         __syncthreads();
         return false;
     }
-    // ---- publish (wave 3) ----
-    if (wave == 3) {
+    // ---- publish (last wave): row values first, then the header {pos, a_pk} ----
+    if (wave == PANEL_WAVES - 1) {
         if (cp != POS_NONE) {
             if (lane >= k && lane < NB)
-                Gran<T>::store(rowrec + (size_t)g * PS_ROW_WORDS + lane * GN, tag, sh.crow[cw * NB + lane]);
-            if (lane == 0) Gran<T>::store(hdr + (size_t)g * PS_HDR_WORDS + 1, tag, sh.crow[cw * NB + k]);
+                Gran<T>::store(rowrec + (size_t)g * PS_ROW_WORDS + lane * GN, tag, sh->crow[cw * NB + lane]);
+            if (lane == 0) Gran<T>::store(hdr + (size_t)g * PS_HDR_WORDS + 1, tag, sh->crow[cw * NB + k]);
         }
         if (lane == 0) gran_store(hdr + (size_t)g * PS_HDR_WORDS, tag, cp);
     }
-    // ---- poll all headers, pick the global winner, fetch its row (wave 0) ----
+    // ---- poll all headers (all granules of a header in flight together), pick the winner, fetch its row (wave 0) ----
     if (wave == 0) {
         bool timed_out = false;
         T gv = T(-1);
@@ -296,31 +375,30 @@ __device__ __noinline__ bool pivot_exchange(const PanelArgs<T>& p, const PivotSh
         for (int x = lane; x < G; x += 64) {
             const u64* hx = hdr + (size_t)x * PS_HDR_WORDS;
             int spins = 0;
-            u64 h0;
             for (;;) {
-                h0 = gran_load(hx);
-                if ((unsigned)(h0 >> 32) == tag) break;
+                const u64 h0 = gran_load(hx);
+                T xv = T(0);
+                const bool vok = Gran<T>::load(hx + 1, tag, xv);
+                const unsigned xp = (unsigned)h0;
+                if ((unsigned)(h0 >> 32) == tag && (xp == POS_NONE || vok)) {
+                    if (xp != POS_NONE) {
+                        const T av = tabs(xv);
+                        const T key = (av > T(0)) ? av : T(0);
+                        if (better<T>(key, xp, gv, gp)) { gv = key; gp = xp; gg = x; }
+                    }
+                    break;
+                }
                 if (++spins > SPIN_LIMIT) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            const unsigned xp = (unsigned)h0;
-            if (!timed_out && xp != POS_NONE) {
-                T xv = T(0);
-                spins = 0;
-                while (!Gran<T>::load(hx + 1, tag, xv)) {
-                    if (++spins > SPIN_LIMIT) { timed_out = true; break; }
-                }
-                const T av = tabs(xv);
-                const T key = (av > T(0)) ? av : T(0);
-                if (better<T>(key, xp, gv, gp)) { gv = key; gp = xp; gg = x; }
-            }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const T ov = __shfl_xor(gv, off);
-            const unsigned op = (unsigned)__shfl_xor((int)gp, off);
-            const int og = __shfl_xor(gg, off);
-            if (better<T>(ov, op, gv, gp)) { gv = ov; gp = op; gg = og; }
+        {   // global winner: max key, lowest position; its workgroup index travels via the winning lane
+            const T mykey = gv;
+            const unsigned mypos = gp;
+            wave_argmax<T>(gv, gp);
+            const u64 who = __ballot(mykey == gv && mypos == gp && mypos != POS_NONE);
+            const int wl = who ? (__ffsll((long long)who) - 1) : 0;
+            gg = __builtin_amdgcn_readlane(gg, wl);
         }
         if (lane >= k && lane < NB && gp != POS_NONE) {
             T xv = T(0);
@@ -328,101 +406,123 @@ __device__ __noinline__ bool pivot_exchange(const PanelArgs<T>& p, const PivotSh
             while (!Gran<T>::load(rowrec + (size_t)gg * PS_ROW_WORDS + lane * GN, tag, xv)) {
                 if (++spins > SPIN_LIMIT) { timed_out = true; break; }
             }
-            sh.prow[lane] = xv;
+            sh->prow[lane] = xv;
         }
-        if (lane == 0) *sh.win = gp;
+        if (lane == 0) sh->win = gp;
         if (__any(timed_out)) {
             if (lane == 0) {
-                __hip_atomic_store((u64*)(p.info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *sh.win = POS_NONE;
-                *sh.dead = 1;
+                __hip_atomic_store((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh->win = POS_NONE;
+                sh->dead = 1;
             }
         }
     }
     __syncthreads();
-    return *sh.dead != 0;
+    return sh->dead != 0;
+}
+
+// ---- the per-step code is split so that ONLY the register-indexed parts (row dump, rank-1 update) are unrolled 64x.
+// Everything else lives in two out-of-line functions shared by all steps: the unrolled body is executed exactly once
+// per launch, i.e. it streams through the instruction cache -- at ~500 instructions per step (256 KB of code) the
+// kernel was instruction-fetch bound (2 us per step with no exchange at all); now it is ~90 instructions per step.
+
+// Front half: candidate key of this thread's row, wave-wide argmax, wave leader records (key,pos).  Returns the wave's
+// winning position (POS_NONE if the wave has no active row).
+template <typename T>
+__device__ __noinline__ unsigned step_front(PivotLds<T>* sh, T aval, unsigned pos, bool act, int lane, int wave)
+{
+    T key = T(-1);
+    unsigned p = POS_NONE;
+    if (act) {
+        const T v = tabs(aval);
+        key = (v > T(0)) ? v : T(0);  // NaN and 0 -> 0: never preferred, ties -> lowest position (src/lu.jl:298-304)
+        p = pos;
+    }
+    wave_argmax<T>(key, p);
+    if (lane == 0) { sh->wval[wave] = key; sh->wpos[wave] = p; }
+    return p;
+}
+
+template <typename T>
+struct MidOut {
+    T scale;         // 1/pivot (or 1 when the pivot is exactly zero)
+    unsigned pos;    // this thread's row position after the interchange
+    unsigned flags;  // bit0: apply the update to this row, bit1: row still active, bit2: give up (timeout)
+};
+
+// Middle: barrier, cross-workgroup exchange, bookkeeping of positions / ipiv / info.
+template <typename T>
+__device__ __noinline__ MidOut<T> step_mid(PivotLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch,
+                                           int G, int k, int r0, int g, int tid, unsigned pos, bool act)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    RFLU_STAMP(scratch, k, 3, g, tid);
+    const bool dead = pivot_exchange<T>(sh, scratch, info, epoch, G, k, g, lane, wave);
+    RFLU_STAMP(scratch, k, 4, g, tid);
+    MidOut<T> o;
+    o.scale = T(1);
+    o.pos = pos;
+    o.flags = (act ? 2u : 0u) | (dead ? 4u : 0u);
+    const unsigned win_pos = sh->win;
+    if (win_pos == POS_NONE) return o;
+    const T piv = sh->prow[k];
+    const bool has = (piv != T(0));
+    const unsigned kpos = (unsigned)(r0 + k);
+    if (g == 0 && tid == 0) {
+        ipiv[r0 + k] = (int64_t)win_pos + 1;
+        sh->piv[k] = (int)win_pos;
+        if (!has && info[0] == 0) info[0] = (int64_t)r0 + k + 1;
+    }
+    if (has) o.scale = T(1) / piv;
+    if (act) {
+        if (pos == win_pos) {
+            o.pos = kpos;      // pivot row: final position r0+k, no further updates
+            o.flags &= ~2u;
+        } else {
+            if (pos == kpos) o.pos = win_pos;  // displaced row takes the pivot's old position
+            o.flags |= 1u;
+        }
+    }
+    return o;
 }
 
 // One pivot step, K a compile-time constant so that every register-array index below is static.
-template <typename T, int RT, int K>
-__device__ __forceinline__ void pivot_step(const PanelArgs<T>& p, const PivotShared<T>& sh, T (&a)[RT][NB],
-                                           unsigned (&pos)[RT], bool (&act)[RT], bool& dead, int g, int tid, int lane,
-                                           int wave)
+template <typename T, int K>
+__device__ __forceinline__ void pivot_step(const PanelArgs<T>& p, PivotLds<T>* sh, T (&a)[NB], unsigned& pos, bool& act,
+                                           bool& dead, int g, int tid, int lane, int wave)
 {
     if (K >= p.w || dead) return;
-
-    // ---- local candidate: key = |a| if > 0 (NaN and 0 -> 0), ties -> lowest position ----
-    T bv = T(-1);
-    unsigned bp = POS_NONE;
+    RFLU_STAMP(p.scratch, K, 0, g, tid);
+    const unsigned wp = step_front<T>(sh, a[K], pos, act, lane, wave);
+    RFLU_STAMP(p.scratch, K, 1, g, tid);
+    if (act && pos == wp) {  // the wave's winning row is dumped to LDS by its owner (columns K..NB-1)
 #pragma unroll
-    for (int q = 0; q < RT; ++q) {
-        if (act[q]) {
-            const T v = tabs(a[q][K]);
-            const T key = (v > T(0)) ? v : T(0);
-            if (better<T>(key, pos[q], bv, bp)) { bv = key; bp = pos[q]; }
-        }
+        for (int j = K; j < NB; ++j) sh->crow[wave * NB + j] = a[j];
     }
-    T wv = bv;
-    unsigned wp = bp;
+    RFLU_STAMP(p.scratch, K, 2, g, tid);
+    const MidOut<T> o = step_mid<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.r0, g, tid, pos, act);
+    RFLU_STAMP(p.scratch, K, 5, g, tid);
+    pos = o.pos;
+    act = (o.flags & 2u) != 0;
+    dead = (o.flags & 4u) != 0;
+    if (o.flags & 1u) {
+        const T l = a[K] * o.scale;  // reciprocal-multiply (src/lu.jl:317-320); scale == 1 after a zero pivot
+        a[K] = l;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const T ov = __shfl_xor(wv, off);
-        const unsigned op = (unsigned)__shfl_xor((int)wp, off);
-        if (better<T>(ov, op, wv, wp)) { wv = ov; wp = op; }
+        for (int j = K + 1; j < NB; ++j) a[j] -= l * sh->prow[j];
     }
-    // the wave's winning row is dumped to LDS by its owner (columns K..NB-1)
-#pragma unroll
-    for (int q = 0; q < RT; ++q) {
-        if (act[q] && pos[q] == wp) {
-#pragma unroll
-            for (int j = K; j < NB; ++j) sh.crow[wave * NB + j] = a[q][j];
-        }
-    }
-    if (lane == 0) { sh.wval[wave] = wv; sh.wpos[wave] = wp; }
-    __syncthreads();
-
-    dead = pivot_exchange<T>(p, sh, K, g, lane, wave);
-    const unsigned win_pos = *sh.win;
-
-    // ---- bookkeeping + rank-1 update -----------------------------------------------------------------------------
-    if (win_pos != POS_NONE) {
-        const T piv = sh.prow[K];
-        const bool has = (piv != T(0));
-        const unsigned kpos = (unsigned)(p.r0 + K);
-        if (g == 0 && tid == 0) {
-            p.ipiv[p.r0 + K] = (int64_t)win_pos + 1;
-            sh.piv[K] = (int)win_pos;
-            if (!has && p.info[0] == 0) p.info[0] = (int64_t)p.r0 + K + 1;
-        }
-        const T inv = has ? T(1) / piv : T(1);
-#pragma unroll
-        for (int q = 0; q < RT; ++q) {
-            if (act[q]) {
-                if (pos[q] == win_pos) {
-                    act[q] = false;  // pivot row: final position r0+K, no further updates
-                    pos[q] = kpos;
-                } else {
-                    if (pos[q] == kpos) pos[q] = win_pos;  // displaced row takes the pivot's old position
-                    T l = a[q][K];
-                    if (has) l *= inv;
-                    a[q][K] = l;
-#pragma unroll
-                    for (int j = K + 1; j < NB; ++j) a[q][j] -= l * sh.prow[j];
-                }
-            }
-        }
-    }
+    RFLU_STAMP(p.scratch, K, 6, g, tid);
 }
 
-template <typename T, int RT, int K0, int K1>
+template <typename T, int K0, int K1>
 struct PivotSteps {
-    static __device__ __forceinline__ void run(const PanelArgs<T>& p, const PivotShared<T>& sh, T (&a)[RT][NB],
-                                               unsigned (&pos)[RT], bool (&act)[RT], bool& dead, int g, int tid,
-                                               int lane, int wave)
+    static __device__ __forceinline__ void run(const PanelArgs<T>& p, PivotLds<T>* sh, T (&a)[NB], unsigned& pos,
+                                               bool& act, bool& dead, int g, int tid, int lane, int wave)
     {
         if constexpr (K0 < K1) {
-            pivot_step<T, RT, K0>(p, sh, a, pos, act, dead, g, tid, lane, wave);
-            PivotSteps<T, RT, K0 + 1, K1>::run(p, sh, a, pos, act, dead, g, tid, lane, wave);
+            pivot_step<T, K0>(p, sh, a, pos, act, dead, g, tid, lane, wave);
+            PivotSteps<T, K0 + 1, K1>::run(p, sh, a, pos, act, dead, g, tid, lane, wave);
         }
     }
 };
@@ -430,48 +530,33 @@ struct PivotSteps {
 template <typename T, int RT>
 __global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_kernel(PanelArgs<T> p)
 {
-    __shared__ T s_tile[64 * TILE_LD];
-    __shared__ T s_crow[4 * NB];
-    __shared__ T s_prow[NB];
-    __shared__ T s_wval[4];
-    __shared__ unsigned s_wpos[4];
-    __shared__ unsigned s_win;
-    __shared__ int s_dead;
-    __shared__ int s_piv[NB];
-    __shared__ int s_spos[64];
-    __shared__ int s_rows[2 * NB];
-    __shared__ int s_content[2 * NB];
+    static_assert(RT == 1, "one row per thread");
+    __shared__ PivotLds<T> s_lds;
+    PivotLds<T>* const sh = &s_lds;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x;
     const int w = p.w;
-    const int row_base = p.r0 + g * (PANEL_THREADS * RT);
+    const int row_base = p.r0 + g * PANEL_THREADS;
 
-    T a[RT][NB];
-    unsigned pos[RT];   // current row position of this thread's row; POS_NONE for rows beyond m
-    bool act[RT];       // still a pivot candidate (not yet chosen, inside the matrix)
-#pragma unroll
-    for (int q = 0; q < RT; ++q) {
-        const int row = row_base + q * PANEL_THREADS + tid;
-        act[q] = row < p.m;
-        pos[q] = act[q] ? (unsigned)row : POS_NONE;
-    }
-    if (tid == 0) s_dead = 0;
-    load_rows<T, RT>(p.R, p.ld, row_base, p.m, p.c0, w, a, s_tile, wave, lane);
+    T a[1][NB];
+    const int row = row_base + tid;
+    bool act = row < p.m;                          // still a pivot candidate (not yet chosen, inside the matrix)
+    unsigned pos = act ? (unsigned)row : POS_NONE; // current row position of this thread's row
+    if (tid == 0) sh->dead = 0;
+    load_rows<T, 1>(p.R, p.ld, row_base, p.m, p.c0, w, a, sh->tile, wave, lane);
 
-    PivotShared<T> sh;
-    sh.crow = s_crow; sh.prow = s_prow; sh.wval = s_wval; sh.wpos = s_wpos; sh.win = &s_win; sh.dead = &s_dead;
-    sh.piv = s_piv;
     bool dead = false;  // set (workgroup-uniformly) after a timeout: skip the remaining steps quickly
-    PivotSteps<T, RT, 0, NB>::run(p, sh, a, pos, act, dead, g, tid, lane, wave);
+    PivotSteps<T, 0, NB>::run(p, sh, a[0], pos, act, dead, g, tid, lane, wave);
 
-    store_rows<T, RT>(p.R, p.ld, p.c0, w, a, pos, s_tile, s_spos, wave, lane);
+    unsigned posv[1] = {pos};
+    store_rows<T, 1>(p.R, p.ld, p.c0, w, a, posv, sh->tile, sh->spos, wave, lane);
 
-    if (g == 0 && wave == 3) {
+    if (g == 0 && wave == PANEL_WAVES - 1) {
         __threadfence_block();
         const int chunk = p.r0 / NB;
-        perm_build_wave(s_piv, p.r0, w, lane, s_rows, s_content, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
-                        p.pm_src + (size_t)chunk * 2 * NB);
+        perm_build_wave(sh->piv, p.r0, w, lane, sh->rows, sh->content, p.pm_cnt + chunk,
+                        p.pm_dst + (size_t)chunk * 2 * NB, p.pm_src + (size_t)chunk * 2 * NB);
     }
 }
 
@@ -486,7 +571,7 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_nopivot_top_kernel(PanelA
     __shared__ T s_U[NB * TILE_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w = p.w;
-    for (int rr = wave; rr < NB; rr += 4) {
+    for (int rr = wave; rr < NB; rr += PANEL_WAVES) {
         T v = T(0);
         if (rr < w && lane < w) v = p.R[(int64_t)(p.r0 + rr) * p.ld + p.c0 + lane];
         s_U[rr * TILE_LD + lane] = v;
@@ -511,7 +596,7 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_nopivot_top_kernel(PanelA
         if (tid == 0 && !has && p.info[0] == 0) p.info[0] = (int64_t)p.r0 + k + 1;
         __syncthreads();
     }
-    for (int rr = wave; rr < w; rr += 4)
+    for (int rr = wave; rr < w; rr += PANEL_WAVES)
         if (lane < w) p.R[(int64_t)(p.r0 + rr) * p.ld + p.c0 + lane] = s_U[rr * TILE_LD + lane];
 }
 
@@ -550,7 +635,7 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_nopivot_rows_kernel(Panel
     const int w = p.w;
     const int row_base = p.r0 + w + g * (PANEL_THREADS * RT);
 
-    for (int rr = wave; rr < NB; rr += 4) {
+    for (int rr = wave; rr < NB; rr += PANEL_WAVES) {
         T v = T(0);
         if (rr < w && lane < w) v = p.R[(int64_t)(p.r0 + rr) * p.ld + p.c0 + lane];
         s_U[rr * TILE_LD + lane] = v;
@@ -613,6 +698,7 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
 template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 template int launch_panel<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 
-size_t panel_scratch_bytes() { return PS_TOTAL_WORDS * sizeof(u64); }
+size_t panel_scratch_bytes() { return (PS_TOTAL_WORDS + 8 * NB) * sizeof(u64); }  // + room for RFLU_PANEL_TRACE stamps
+size_t panel_trace_offset_bytes() { return PS_TOTAL_WORDS * sizeof(u64); }
 
 }  // namespace rflu

@@ -15,7 +15,7 @@
 namespace rflu {
 
 constexpr int NB = 64;            // leaf panel width == pivot chunk size (columns per cooperative panel kernel)
-constexpr int PANEL_THREADS = 256;
+constexpr int PANEL_THREADS = 512;  // 8 waves = 2 per SIMD: the second wave fills the issue gaps of a latency-bound step
 constexpr int MAX_PANEL_WGS = 256;  // one workgroup per CU at most: all must be co-resident (they spin on each other)
 
 // ---- error plumbing -------------------------------------------------------------------------------------------------
@@ -113,6 +113,7 @@ int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64
 // fold the interchanges ipiv[k0..k1) (k0 a multiple of NB) into per-chunk row-move lists
 int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, int64_t m);
 size_t panel_scratch_bytes();
+size_t panel_trace_offset_bytes();
 template <typename T>
 int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0, int64_t w, int64_t* ipiv, int pivot);
 template <typename T>

@@ -19,11 +19,13 @@ struct TrsmRow {
     static __device__ __forceinline__ void run(const T* sL, T (&x)[NB])
     {
         if constexpr (I < NB) {
-            T s = x[I];
+            // four independent partial sums: a dependent fp64 FMA chain costs ~10+ cycles per link on one wave/SIMD
+            T acc[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-            for (int k = 0; k < I; ++k) s -= sL[I * NB + k] * x[k];
-            // pin row I's FMA chain before the next row's LDS reads: hipcc otherwise hoists all 2016 reads above the
-            // dependent FMA chains and spills ~14 KB per lane
+            for (int k = 0; k < I; ++k) acc[k & 3] += sL[I * NB + k] * x[k];
+            T s = x[I] - ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+            // pin row I's arithmetic before the next row's LDS reads: hipcc otherwise hoists all 2016 reads above the
+            // FMA chains and spills ~14 KB per lane
             asm volatile("" : "+v"(s) : : "memory");
             x[I] = s;
             TrsmRow<T, I + 1>::run(sL, x);
@@ -37,16 +39,25 @@ __global__ void __launch_bounds__(128) trsm_base_kernel(int nb, int64_t nrhs, co
 {
     __shared__ T sL[NB * NB];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < NB * NB; idx += 128) {
-        const int i = idx / NB, k = idx % NB;
-        sL[idx] = (i < nb && k < i) ? L[(int64_t)i * ldl + k] : T(0);
+    {
+        T tmp[NB * NB / 128];
+#pragma unroll
+        for (int it = 0; it < NB * NB / 128; ++it) {  // all 32 loads in flight together
+            const int idx = it * 128 + tid;
+            const int i = idx >> 6, k = idx & 63;
+            tmp[it] = (i < nb && k < i) ? L[(int64_t)i * ldl + k] : T(0);
+        }
+#pragma unroll
+        for (int it = 0; it < NB * NB / 128; ++it) sL[it * 128 + tid] = tmp[it];
+    }
+    const int64_t j = (int64_t)blockIdx.x * 128 + tid;
+    T x[NB];
+    if (j < nrhs) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) x[i] = (i < nb) ? B[(int64_t)i * ldb + j] : T(0);
     }
     __syncthreads();
-    const int64_t j = (int64_t)blockIdx.x * 128 + tid;
     if (j >= nrhs) return;
-    T x[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) x[i] = (i < nb) ? B[(int64_t)i * ldb + j] : T(0);
     TrsmRow<T, 1>::run(sL, x);
 #pragma unroll
     for (int i = 0; i < NB; ++i)

@@ -1,0 +1,198 @@
+"""1-D block-column LU over the GPUs of one node: one process per GPU, ``torch.distributed`` (RCCL over xGMI).
+
+The reference has no distributed path (zero collective call sites); this is the partition the
+north star asks for.  Structure:
+  * the n x n matrix is cut into block columns of ``block`` (a multiple of 64) columns; block b lives on rank
+    ``b % world`` as part of that rank's row-major slab (all n rows x its local columns) -- cyclic, so the shrinking
+    trailing matrix stays balanced;
+  * per block column: the owner factors the tall panel with the single-GPU recursive path (``rflu_panel_rm_*``:
+    cooperative leaf panels + TRSM/GEMM inside the panel), packs {L\\U panel, ipiv segment, info} and broadcasts it --
+    the ONLY collective of the path, one message per block column;
+  * every rank then applies the interchanges to its local columns (``rflu_laswp_rm_*``), solves the block row
+    (``rflu_trsm_rm_*``) and updates its trailing columns (``rflu_gemm_rm_*``, MFMA).  No reductions are needed.
+The kernels are reached through an ``ops`` object so that the orchestration (ownership, message contents, update order)
+is exercised on CPU under gloo in tests/test_distributed.py with a NumPy stand-in for ``ops``; the product path uses
+``HipOps`` (C ABI of librflu.so) only.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+NB = 64
+
+
+class HipOps:
+    """The four kernels of the path on row-major device slabs, through the C ABI (include/rflu.h)."""
+
+    def __init__(self, handle, sfx: str):
+        self.h = handle
+        self.sfx = sfx
+        self.es = 8 if sfx == "f64" else 4
+
+    def _p(self, t, off=0):
+        return ctypes.c_void_p(t.data_ptr() + off * self.es)
+
+    def panel(self, R, ld, m, r0, c0, w, ipiv, pivot) -> int:
+        info = ctypes.c_int64(0)
+        self.h.call(f"rflu_panel_rm_{self.sfx}_dev", m, r0, c0, w, self._p(R), ld, ctypes.c_void_p(ipiv.data_ptr()),
+                    int(pivot), ctypes.byref(info))
+        return int(info.value)
+
+    def laswp(self, R, ld, m, c0, ncols, ipiv, k0, k1):
+        if ncols > 0 and k1 > k0:
+            self.h.call(f"rflu_laswp_rm_{self.sfx}_dev", self._p(R), ld, m, c0, ncols, ctypes.c_void_p(ipiv.data_ptr()), k0, k1)
+
+    def trsm(self, n, nrhs, L, l_off, ldl, B, b_off, ldb):
+        if n > 0 and nrhs > 0:
+            self.h.call(f"rflu_trsm_rm_{self.sfx}_dev", n, nrhs, self._p(L, l_off), ldl, self._p(B, b_off), ldb)
+
+    def gemm(self, M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc):
+        if M > 0 and N > 0 and K > 0:
+            self.h.call(f"rflu_gemm_rm_{self.sfx}_dev", M, N, K, self._p(A, a_off), lda, self._p(B, b_off), ldb,
+                        self._p(C, c_off), ldc)
+
+    def fill(self, R, ld, m, w, c0, seed, n_global, j0, diag_add=0.0):
+        self.h.call(f"rflu_fill_uniform_{self.sfx}_dev", self._p(R, c0), m, w, ld, 1, seed, n_global, 0, j0, float(diag_add))
+
+
+def block_layout(n: int, block: int, world: int):
+    """[(global col start, width, owner rank, local col offset on the owner)] for every block column."""
+    out = []
+    nblocks = (n + block - 1) // block
+    local_off = [0] * world
+    for b in range(nblocks):
+        j0 = b * block
+        w = min(block, n - j0)
+        owner = b % world
+        out.append((j0, w, owner, local_off[owner]))
+        local_off[owner] += w
+    return out, local_off
+
+
+class BlockColumnLU:
+    """Factor an n x n matrix distributed by block columns.  ``factor()`` is one step of bench.py's --gpus N path."""
+
+    def __init__(self, ops, n, dtype, rank, world, device, *, block=512, pivot=True, seed=12, diag_add=0.0, group=None):
+        if block % NB:
+            raise ValueError("block must be a multiple of 64")
+        self.ops, self.n, self.rank, self.world, self.device = ops, n, rank, world, device
+        self.block, self.pivot, self.seed, self.diag_add, self.group = block, pivot, seed, diag_add, group
+        self.dtype = dtype
+        self.layout, local_cols = block_layout(n, block, world)
+        self.n_loc = local_cols[rank]
+        self.ld = max(16, (self.n_loc + 15) // 16 * 16)
+        self.R = torch.zeros((n, self.ld), dtype=dtype, device=device)       # this rank's slab, row-major
+        self.ipiv = torch.zeros(n, dtype=torch.int64, device=device)          # full pivot vector on every rank
+        wmax = min(block, n)
+        # one message per block column: [panel rows j0..n) x w | ipiv segment | info], all carried as the matrix dtype's
+        # bytes would lose int64 pivots for Float32, so pivots travel in a second int64 message appended to the first
+        self.pbuf = torch.zeros(n * wmax, dtype=dtype, device=device)
+        self.meta = torch.zeros(wmax + 1, dtype=torch.int64, device=device)   # ipiv segment + info
+        self.info = 0
+
+    # ---- input -------------------------------------------------------------------------------------------------------
+    def regenerate(self):
+        for (j0, w, owner, lc) in self.layout:
+            if owner == self.rank:
+                self.ops.fill(self.R, self.ld, self.n, w, lc, self.seed, self.n, j0, self.diag_add)
+
+    def load_global(self, A):
+        """Scatter a full (n x n) host matrix into the slabs (tests)."""
+        for (j0, w, owner, lc) in self.layout:
+            if owner == self.rank:
+                self.R[:, lc:lc + w] = torch.as_tensor(np.ascontiguousarray(A[:, j0:j0 + w]), dtype=self.dtype).to(self.device)
+
+    # ---- the factorization ---------------------------------------------------------------------------------------------
+    def factor(self):
+        n, ld, ops = self.n, self.ld, self.ops
+        self.info = 0
+        if not self.pivot:
+            self.ipiv.copy_(torch.arange(1, n + 1, dtype=torch.int64, device=self.device))
+        for (j0, w, owner, lc) in self.layout:
+            rows = n - j0
+            panel = self.pbuf[: rows * w].view(rows, w)
+            if self.rank == owner:
+                info = ops.panel(self.R, ld, n, j0, lc, w, self.ipiv, self.pivot)
+                panel.copy_(self.R[j0:, lc:lc + w])
+                self.meta[:w].copy_(self.ipiv[j0:j0 + w])
+                self.meta[w] = info
+            # ---- the one exchange step of the path: panel + pivots, owner -> everybody ----
+            if self.world > 1:
+                src = owner if self.group is None else dist.get_global_rank(self.group, owner)
+                dist.broadcast(panel, src=src, group=self.group)
+                dist.broadcast(self.meta[: w + 1], src=src, group=self.group)
+            if self.rank != owner:
+                self.ipiv[j0:j0 + w].copy_(self.meta[:w])
+            info = int(self.meta[w].item()) if self.world > 1 or self.rank == owner else 0
+            if info != 0 and self.info == 0:
+                self.info = info
+            # ---- local columns: left of the panel (finished L columns) and right of it (trailing) ----
+            if self.rank == owner:
+                left_end, right_start = lc, lc + w
+            else:
+                right_start = sum(ww for (jj, ww, oo, _) in self.layout if oo == self.rank and jj < j0)
+                left_end = right_start
+            nt = self.n_loc - right_start
+            if self.pivot:
+                ops.laswp(self.R, ld, n, 0, left_end, self.ipiv, j0, j0 + w)
+                ops.laswp(self.R, ld, n, right_start, nt, self.ipiv, j0, j0 + w)
+            if nt > 0:
+                ops.trsm(w, nt, self.pbuf, 0, w, self.R, j0 * ld + right_start, ld)
+                ops.gemm(rows - w, nt, w, self.pbuf, w * w, w, self.R, j0 * ld + right_start, ld,
+                         self.R, (j0 + w) * ld + right_start, ld)
+        return self.info
+
+    # ---- results -------------------------------------------------------------------------------------------------------
+    def gather_factors(self):
+        """Full packed L\\U on every rank as a host array (tests / small sizes only)."""
+        full = torch.zeros((self.n, self.n), dtype=self.dtype, device=self.device)
+        for (j0, w, owner, lc) in self.layout:
+            blk = torch.zeros((self.n, w), dtype=self.dtype, device=self.device)
+            if owner == self.rank:
+                blk.copy_(self.R[:, lc:lc + w])
+            if self.world > 1:
+                src = owner if self.group is None else dist.get_global_rank(self.group, owner)
+                dist.broadcast(blk, src=src, group=self.group)
+            full[:, j0:j0 + w] = blk
+        return full.cpu().numpy()
+
+    def matvec_residual(self, trials: int = 2) -> float:
+        """max over random x of ||P*A*x - L*(U*x)|| / ||A*x||, A regenerated from the seed; O(n^2) per rank.
+        Checker for sizes where the n^3 residual is not affordable (uses torch ops, not the product's kernels)."""
+        n, dev = self.n, self.device
+        LU = self.R[:, : self.n_loc].clone()
+        self.regenerate()
+        A = self.R[:, : self.n_loc].clone()
+        self.R[:, : self.n_loc] = LU
+        cols = torch.cat([torch.arange(j0, j0 + w, device=dev) for (j0, w, o, _) in self.layout if o == self.rank]) \
+            if self.n_loc else torch.zeros(0, dtype=torch.int64, device=dev)
+        rows = torch.arange(n, device=dev)[:, None]
+        Uloc = torch.where(rows <= cols[None, :], LU, torch.zeros_like(LU))
+        Lloc = torch.where(rows > cols[None, :], LU, torch.zeros_like(LU))
+        perm = np.arange(n)
+        for i, t in enumerate(self.ipiv.cpu().numpy()):
+            j = int(t) - 1
+            if j != i:
+                perm[i], perm[j] = perm[j], perm[i]
+        perm = torch.from_numpy(perm).to(dev)
+        worst = 0.0
+        gen = torch.Generator(device="cpu").manual_seed(1234)
+        for _ in range(trials):
+            x = torch.rand(n, dtype=torch.float64, generator=gen).to(dev).to(self.dtype)
+            xl = x[cols]
+            ax = A.to(torch.float64) @ xl.to(torch.float64)
+            ux = Uloc.to(torch.float64) @ xl.to(torch.float64)
+            if self.world > 1:
+                dist.all_reduce(ax, group=self.group)
+                dist.all_reduce(ux, group=self.group)
+            lz = Lloc.to(torch.float64) @ ux[cols] + torch.zeros(n, dtype=torch.float64, device=dev)
+            if self.world > 1:
+                dist.all_reduce(lz, group=self.group)
+            lz = lz + ux  # unit diagonal of L
+            r = torch.linalg.norm(ax[perm] - lz) / torch.linalg.norm(ax)
+            worst = max(worst, float(r.item()))
+        return worst

@@ -173,3 +173,28 @@ def test_large_properties_on_device():
     PA = torch.from_numpy(A).to(LUm.device)[perm]
     res = (torch.linalg.norm(L @ U - PA) / torch.linalg.norm(PA)).item()
     assert res < 1e-12, res
+
+
+@pytest.mark.parametrize("n,block,pivot", [(700, 128, True), (1000, 256, True), (300, 64, False)])
+def test_block_column_driver_single_rank_hip_ops(n, block, pivot):
+    # the multi-GPU driver with the real HIP building blocks (rflu_panel_rm with w > 64, laswp_rm, trsm_rm, gemm_rm),
+    # world = 1 so no collective is needed: pivots bit-exact vs the oracle, factors to rounding
+    from recursivefactorization.jl_amd import _ffi
+    from recursivefactorization.jl_amd.distributed import BlockColumnLU, HipOps
+
+    diag = 0.0 if pivot else 10.0
+    h = _ffi.default_handle(0)
+    h.set_stream(None)
+    job = BlockColumnLU(HipOps(h, "f64"), n, torch.float64, 0, 1, torch.device("cuda:0"), block=block, pivot=pivot,
+                        seed=12, diag_add=diag)
+    job.regenerate()
+    torch.cuda.synchronize()
+    A = O.np_uniform(n, n, 12) + diag * np.eye(n)
+    assert np.array_equal(job.R[:, :n].cpu().numpy(), A)
+    info = job.factor()
+    torch.cuda.synchronize()
+    Fo, ipo, infoo = O.lu(A, pivot=pivot)
+    assert info == infoo == 0
+    assert np.array_equal(job.ipiv.cpu().numpy(), ipo)
+    assert np.max(np.abs(job.gather_factors() - Fo)) < 50 * tol_E(A)
+    assert job.matvec_residual() < 1e-12

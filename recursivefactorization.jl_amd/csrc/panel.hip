@@ -33,50 +33,80 @@ constexpr unsigned POS_NONE = 0x7fffffffu;
 constexpr int SPIN_LIMIT = 1 << 20;
 constexpr int TILE_LD = NB + 1;
 constexpr int PANEL_WAVES = PANEL_THREADS / 64;
+static_assert(PANEL_WAVES == 8, "the workgroup-winner trees in step_a are written for 8 waves");
 
-__device__ __forceinline__ void gran_store(u64* p, unsigned tag, unsigned v)
+// ---- cross-workgroup records: data-tagged granules ------------------------------------------------------------------
+// A granule is 8 bytes {payload dword, tag dword}; a Float64 value travels as two granules written by ONE 16-byte
+// write-through store (buffer_store_dwordx4 ... sc1) and read by one 16-byte sc1 load; the reader accepts a value only
+// when both tags equal the step's tag, so no flag, fence or barrier orders the exchange
+// (cdna_hip_programming.md Guideline 16, form R2).
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+constexpr int AUX_SC1 = 16;
+
+constexpr unsigned PS_HDR_BYTES = 32;                       // per workgroup: {pos,tag | a_pk granule(s)}
+constexpr unsigned PS_VAL_BYTES = 16;                       // per row value (Float32 uses the first 8)
+constexpr unsigned PS_ROW_BYTES = NB * PS_VAL_BYTES;        // per workgroup candidate row
+constexpr unsigned PS_HDR_REGION = MAX_PANEL_WGS * PS_HDR_BYTES;
+constexpr unsigned PS_BUF_BYTES = PS_HDR_REGION + MAX_PANEL_WGS * PS_ROW_BYTES;  // one parity buffer
+constexpr size_t PS_TOTAL_WORDS = 2 * (size_t)PS_BUF_BYTES / 8;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t scratch_rsrc(u64* scratch)
 {
-    __hip_atomic_store(p, ((u64)tag << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 gran_load(const u64* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 2 * PS_BUF_BYTES, 0x00020000);
 }
 
 template <typename T>
 struct Gran;
 template <>
 struct Gran<double> {
-    static constexpr int N = 2;
-    static __device__ __forceinline__ void store(u64* p, unsigned tag, double v) {
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, double v) {
         const u64 b = (u64)__double_as_longlong(v);
-        gran_store(p, tag, (unsigned)(b >> 32));
-        gran_store(p + 1, tag, (unsigned)b);
+        const u4v x = {(unsigned)(b >> 32), tag, (unsigned)b, tag};
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, AUX_SC1);
     }
-    static __device__ __forceinline__ bool load(const u64* p, unsigned tag, double& v) {
-        const u64 a = gran_load(p), b = gran_load(p + 1);
-        v = __longlong_as_double((long long)(((a & 0xffffffffull) << 32) | (b & 0xffffffffull)));
-        return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+    static __device__ __forceinline__ bool load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, double& v) {
+        const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
+        v = __longlong_as_double((long long)(((u64)x[0] << 32) | (u64)x[2]));
+        return x[1] == tag && x[3] == tag;
+    }
+    static __device__ __forceinline__ void store_hdr(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned pos, double a) {
+        const u64 b = (u64)__double_as_longlong(a);
+        const u4v x = {pos, tag, (unsigned)(b >> 32), tag};
+        const u4v y = {(unsigned)b, tag, 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(y, r, off + 16, 0, AUX_SC1);
+    }
+    static __device__ __forceinline__ bool load_hdr(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned& pos, double& a) {
+        const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
+        const u4v y = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, AUX_SC1);
+        pos = x[0];
+        a = __longlong_as_double((long long)(((u64)x[2] << 32) | (u64)y[0]));
+        return x[1] == tag && x[3] == tag && y[1] == tag;
     }
 };
 template <>
 struct Gran<float> {
-    static constexpr int N = 1;
-    static __device__ __forceinline__ void store(u64* p, unsigned tag, float v) { gran_store(p, tag, __float_as_uint(v)); }
-    static __device__ __forceinline__ bool load(const u64* p, unsigned tag, float& v) {
-        const u64 a = gran_load(p);
-        v = __uint_as_float((unsigned)a);
-        return (unsigned)(a >> 32) == tag;
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, float v) {
+        const u2v x = {__float_as_uint(v), tag};
+        __builtin_amdgcn_raw_buffer_store_b64(x, r, off, 0, AUX_SC1);
+    }
+    static __device__ __forceinline__ bool load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, float& v) {
+        const u2v x = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, AUX_SC1);
+        v = __uint_as_float(x[0]);
+        return x[1] == tag;
+    }
+    static __device__ __forceinline__ void store_hdr(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned pos, float a) {
+        const u4v x = {pos, tag, __float_as_uint(a), tag};
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, AUX_SC1);
+    }
+    static __device__ __forceinline__ bool load_hdr(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned& pos, float& a) {
+        const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
+        pos = x[0];
+        a = __uint_as_float(x[2]);
+        return x[1] == tag && x[3] == tag;
     }
 };
-
-// scratch layout (u64 words), per parity buffer b in {0,1}:
-//   hdr [b][g][4]        : {tag,pos}, a_pk granule(s), pad        -- polled by everybody
-//   row [b][g][NB*2]     : candidate row values, column j at word j*Gran::N
-constexpr size_t PS_HDR_WORDS = 4;
-constexpr size_t PS_ROW_WORDS = (size_t)NB * 2;
-constexpr size_t PS_BUF_WORDS = (size_t)MAX_PANEL_WGS * (PS_HDR_WORDS + PS_ROW_WORDS);
-constexpr size_t PS_TOTAL_WORDS = 2 * PS_BUF_WORDS;
 
 // Optional step tracing (compile with -DRFLU_PANEL_TRACE; experiment builds only): thread 0 of workgroup 0 stores
 // clock64() stamps into the panel scratch area past the granule records.
@@ -247,12 +277,12 @@ __device__ __forceinline__ void store_rows(T* R, int64_t ld, int c0, int w, cons
 template <typename T>
 struct PivotLds {
     T tile[64 * TILE_LD];   // row <-> register staging
-    T crow[PANEL_WAVES * NB];  // per-wave candidate rows
     T prow[NB];             // pivot row of this step (columns k..NB-1 valid)
     T wval[PANEL_WAVES];
     unsigned wpos[PANEL_WAVES];
-    unsigned win;
+    unsigned win;           // pivot position of this step
     int dead;
+    T scale;                // 1/pivot (1 when the pivot is exactly zero), computed once per step
     int piv[NB];
     int spos[64];
     int rows[2 * NB];
@@ -325,112 +355,18 @@ __device__ __forceinline__ void wave_argmax(T& v, unsigned& p)
     v = m;
 }
 
-// The cross-workgroup part of a pivot step.  Touches no per-thread row registers, so it is kept out of line (one copy
-// instead of 64 in the unrolled step sequence); every argument travels by value in registers.
-// On return sh->win / sh->prow[k..NB) hold the pivot position and row.  Returns true when the workgroup must give up.
+// ---- the per-step code is split so that ONLY the register-indexed parts (row publish, rank-1 update) are unrolled 64x;
+// everything else lives in two out-of-line functions shared by all steps.
+//
+// step_a: candidate key of this thread's row -> wave argmax -> barrier -> workgroup winner (computed redundantly by every
+//         thread from the 8 wave records).  The thread that owns the workgroup's winning row publishes the HEADER
+//         {tag, position, a_pk} at once (the only thing the other workgroups need to pick the pivot) and returns true;
+//         its row values follow from the unrolled caller while the header is already in flight.
 template <typename T>
-__device__ __noinline__ bool pivot_exchange(PivotLds<T>* sh, u64* scratch, int64_t* info, unsigned epoch, int G, int k,
-                                            int g, int lane, int wave)
+__device__ __noinline__ bool step_a(PivotLds<T>* sh, u64* scratch, unsigned epoch, int G, int k, int g, int tid, T aval,
+                                    unsigned pos, bool act)
 {
-    constexpr int GN = Gran<T>::N;
-    const unsigned tag = epoch + (unsigned)k;
-    u64* const hdr = scratch + (size_t)(k & 1) * PS_BUF_WORDS;
-    u64* const rowrec = hdr + (size_t)MAX_PANEL_WGS * PS_HDR_WORDS;
-
-    // ---- workgroup candidate = best of the waves (every thread computes the same answer) ----
-    T cv = sh->wval[0];
-    unsigned cp = sh->wpos[0];
-    int cw = 0;
-#pragma unroll
-    for (int x = 1; x < PANEL_WAVES; ++x) {
-        const T ov = sh->wval[x];
-        const unsigned op = sh->wpos[x];
-        if (better<T>(ov, op, cv, cp)) { cv = ov; cp = op; cw = x; }
-    }
-
-    if (G == 1) {
-        // single workgroup: the candidate is the pivot; no exchange
-        if (wave == 0) {
-            if (lane >= k && lane < NB) sh->prow[lane] = sh->crow[cw * NB + lane];
-            if (lane == 0) sh->win = cp;
-        }
-        __syncthreads();
-        return false;
-    }
-    // ---- publish (last wave): row values first, then the header {pos, a_pk} ----
-    if (wave == PANEL_WAVES - 1) {
-        if (cp != POS_NONE) {
-            if (lane >= k && lane < NB)
-                Gran<T>::store(rowrec + (size_t)g * PS_ROW_WORDS + lane * GN, tag, sh->crow[cw * NB + lane]);
-            if (lane == 0) Gran<T>::store(hdr + (size_t)g * PS_HDR_WORDS + 1, tag, sh->crow[cw * NB + k]);
-        }
-        if (lane == 0) gran_store(hdr + (size_t)g * PS_HDR_WORDS, tag, cp);
-    }
-    // ---- poll all headers (all granules of a header in flight together), pick the winner, fetch its row (wave 0) ----
-    if (wave == 0) {
-        bool timed_out = false;
-        T gv = T(-1);
-        unsigned gp = POS_NONE;
-        int gg = 0;
-        for (int x = lane; x < G; x += 64) {
-            const u64* hx = hdr + (size_t)x * PS_HDR_WORDS;
-            int spins = 0;
-            for (;;) {
-                const u64 h0 = gran_load(hx);
-                T xv = T(0);
-                const bool vok = Gran<T>::load(hx + 1, tag, xv);
-                const unsigned xp = (unsigned)h0;
-                if ((unsigned)(h0 >> 32) == tag && (xp == POS_NONE || vok)) {
-                    if (xp != POS_NONE) {
-                        const T av = tabs(xv);
-                        const T key = (av > T(0)) ? av : T(0);
-                        if (better<T>(key, xp, gv, gp)) { gv = key; gp = xp; gg = x; }
-                    }
-                    break;
-                }
-                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        {   // global winner: max key, lowest position; its workgroup index travels via the winning lane
-            const T mykey = gv;
-            const unsigned mypos = gp;
-            wave_argmax<T>(gv, gp);
-            const u64 who = __ballot(mykey == gv && mypos == gp && mypos != POS_NONE);
-            const int wl = who ? (__ffsll((long long)who) - 1) : 0;
-            gg = __builtin_amdgcn_readlane(gg, wl);
-        }
-        if (lane >= k && lane < NB && gp != POS_NONE) {
-            T xv = T(0);
-            int spins = 0;
-            while (!Gran<T>::load(rowrec + (size_t)gg * PS_ROW_WORDS + lane * GN, tag, xv)) {
-                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
-            }
-            sh->prow[lane] = xv;
-        }
-        if (lane == 0) sh->win = gp;
-        if (__any(timed_out)) {
-            if (lane == 0) {
-                __hip_atomic_store((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh->win = POS_NONE;
-                sh->dead = 1;
-            }
-        }
-    }
-    __syncthreads();
-    return sh->dead != 0;
-}
-
-// ---- the per-step code is split so that ONLY the register-indexed parts (row dump, rank-1 update) are unrolled 64x.
-// Everything else lives in two out-of-line functions shared by all steps: the unrolled body is executed exactly once
-// per launch, i.e. it streams through the instruction cache -- at ~500 instructions per step (256 KB of code) the
-// kernel was instruction-fetch bound (2 us per step with no exchange at all); now it is ~90 instructions per step.
-
-// Front half: candidate key of this thread's row, wave-wide argmax, wave leader records (key,pos).  Returns the wave's
-// winning position (POS_NONE if the wave has no active row).
-template <typename T>
-__device__ __noinline__ unsigned step_front(PivotLds<T>* sh, T aval, unsigned pos, bool act, int lane, int wave)
-{
+    const int lane = tid & 63, wave = tid >> 6;
     T key = T(-1);
     unsigned p = POS_NONE;
     if (act) {
@@ -440,7 +376,39 @@ __device__ __noinline__ unsigned step_front(PivotLds<T>* sh, T aval, unsigned po
     }
     wave_argmax<T>(key, p);
     if (lane == 0) { sh->wval[wave] = key; sh->wpos[wave] = p; }
-    return p;
+    __syncthreads();
+    RFLU_STAMP(scratch, k, 1, g, tid);
+    // workgroup winner from the wave records: max of the keys (tree), then min position among the records holding it --
+    // independent operations instead of a chain of 8 dependent (key,pos) compare-selects
+    T kx[PANEL_WAVES];
+    unsigned px[PANEL_WAVES];
+#pragma unroll
+    for (int x = 0; x < PANEL_WAVES; ++x) { kx[x] = sh->wval[x]; px[x] = sh->wpos[x]; }
+    T cv;
+    {
+        T m01 = tmax(kx[0], kx[1]), m23 = tmax(kx[2], kx[3]), m45 = tmax(kx[4], kx[5]), m67 = tmax(kx[6], kx[7]);
+        cv = tmax(tmax(m01, m23), tmax(m45, m67));
+    }
+    unsigned cp;
+    {
+        unsigned c[PANEL_WAVES];
+#pragma unroll
+        for (int x = 0; x < PANEL_WAVES; ++x) c[x] = (kx[x] == cv) ? px[x] : POS_NONE;
+        cp = min(min(min(c[0], c[1]), min(c[2], c[3])), min(min(c[4], c[5]), min(c[6], c[7])));
+    }
+    const bool mine = act && pos == cp;
+    if (G == 1) {
+        if (mine) {
+            sh->win = cp;
+            sh->scale = (aval != T(0)) ? T(1) / aval : T(1);
+        }
+    } else {
+        const unsigned tag = epoch + (unsigned)k;
+        const unsigned hoff = (unsigned)(k & 1) * PS_BUF_BYTES + (unsigned)g * PS_HDR_BYTES;
+        if (mine) Gran<T>::store_hdr(scratch_rsrc(scratch), hoff, tag, cp, aval);
+        else if (cp == POS_NONE && tid == 0) Gran<T>::store_hdr(scratch_rsrc(scratch), hoff, tag, POS_NONE, T(0));
+    }
+    return mine;
 }
 
 template <typename T>
@@ -450,20 +418,80 @@ struct MidOut {
     unsigned flags;  // bit0: apply the update to this row, bit1: row still active, bit2: give up (timeout)
 };
 
-// Middle: barrier, cross-workgroup exchange, bookkeeping of positions / ipiv / info.
+// step_b: wave 0 polls the G headers (both 16-byte halves of a header in flight together), all workgroups arrive at the
+//         same winner (max |a_pk|, lowest position), fetch the winner's row into LDS; barrier; position / ipiv / info
+//         bookkeeping for this thread's row.
 template <typename T>
-__device__ __noinline__ MidOut<T> step_mid(PivotLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch,
-                                           int G, int k, int r0, int g, int tid, unsigned pos, bool act)
+__device__ __noinline__ MidOut<T> step_b(PivotLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch,
+                                         int G, int k, int r0, int g, int tid, unsigned pos, bool act)
 {
     const int lane = tid & 63, wave = tid >> 6;
+    if (G > 1 && wave == 0) {
+        const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(scratch);
+        const unsigned tag = epoch + (unsigned)k;
+        const unsigned base = (unsigned)(k & 1) * PS_BUF_BYTES;
+        bool timed_out = false;
+        T gv = T(-1);
+        unsigned gp = POS_NONE;
+        int gg = 0;
+        T ga = T(0);  // signed a_pk of this lane's best candidate
+        for (int x = lane; x < G; x += 64) {
+            int spins = 0;
+            for (;;) {
+                unsigned xp;
+                T xv;
+                asm volatile("" ::: "memory");  // the buffer loads are plain (non-atomic) intrinsics: keep them in the loop
+                if (Gran<T>::load_hdr(rs, base + (unsigned)x * PS_HDR_BYTES, tag, xp, xv)) {
+                    if (xp != POS_NONE) {
+                        const T av = tabs(xv);
+                        const T xk = (av > T(0)) ? av : T(0);
+                        if (better<T>(xk, xp, gv, gp)) { gv = xk; gp = xp; gg = x; ga = xv; }
+                    }
+                    break;
+                }
+                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+                if (spins > 4) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        {   // global winner: max key, lowest position; its workgroup index travels via the winning lane
+            const T mykey = gv;
+            const unsigned mypos = gp;
+            wave_argmax<T>(gv, gp);
+            const u64 who = __ballot(mykey == gv && mypos == gp && mypos != POS_NONE);
+            const int wl = who ? (__ffsll((long long)who) - 1) : 0;
+            gg = __builtin_amdgcn_readlane(gg, wl);
+            ga = readlane_val(ga, wl);
+        }
+        RFLU_STAMP(scratch, k, 3, g, tid);
+        if (lane >= k && lane < NB && gp != POS_NONE) {
+            const unsigned roff = base + PS_HDR_REGION + (unsigned)gg * PS_ROW_BYTES + (unsigned)lane * PS_VAL_BYTES;
+            T xv = T(0);
+            int spins = 0;
+            for (;;) {
+                asm volatile("" ::: "memory");
+                if (Gran<T>::load(rs, roff, tag, xv)) break;
+                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+            }
+            sh->prow[lane] = xv;
+        }
+        if (lane == 0) {
+            sh->win = gp;
+            sh->scale = (ga != T(0)) ? T(1) / ga : T(1);  // overlaps with the row fetch above
+        }
+        if (__any(timed_out)) {
+            if (lane == 0) {
+                __hip_atomic_store((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh->win = POS_NONE;
+                sh->dead = 1;
+            }
+        }
+    }
     __syncthreads();
-    RFLU_STAMP(scratch, k, 3, g, tid);
-    const bool dead = pivot_exchange<T>(sh, scratch, info, epoch, G, k, g, lane, wave);
     RFLU_STAMP(scratch, k, 4, g, tid);
     MidOut<T> o;
     o.scale = T(1);
     o.pos = pos;
-    o.flags = (act ? 2u : 0u) | (dead ? 4u : 0u);
+    o.flags = (act ? 2u : 0u) | (sh->dead ? 4u : 0u);
     const unsigned win_pos = sh->win;
     if (win_pos == POS_NONE) return o;
     const T piv = sh->prow[k];
@@ -474,7 +502,7 @@ __device__ __noinline__ MidOut<T> step_mid(PivotLds<T>* sh, u64* scratch, int64_
         sh->piv[k] = (int)win_pos;
         if (!has && info[0] == 0) info[0] = (int64_t)r0 + k + 1;
     }
-    if (has) o.scale = T(1) / piv;
+    o.scale = sh->scale;
     if (act) {
         if (pos == win_pos) {
             o.pos = kpos;      // pivot row: final position r0+k, no further updates
@@ -490,18 +518,29 @@ __device__ __noinline__ MidOut<T> step_mid(PivotLds<T>* sh, u64* scratch, int64_
 // One pivot step, K a compile-time constant so that every register-array index below is static.
 template <typename T, int K>
 __device__ __forceinline__ void pivot_step(const PanelArgs<T>& p, PivotLds<T>* sh, T (&a)[NB], unsigned& pos, bool& act,
-                                           bool& dead, int g, int tid, int lane, int wave)
+                                           bool& dead, int g, int tid)
 {
     if (K >= p.w || dead) return;
     RFLU_STAMP(p.scratch, K, 0, g, tid);
-    const unsigned wp = step_front<T>(sh, a[K], pos, act, lane, wave);
-    RFLU_STAMP(p.scratch, K, 1, g, tid);
-    if (act && pos == wp) {  // the wave's winning row is dumped to LDS by its owner (columns K..NB-1)
-#pragma unroll
-        for (int j = K; j < NB; ++j) sh->crow[wave * NB + j] = a[j];
-    }
+    const bool mine = step_a<T>(sh, p.scratch, p.epoch, p.G, K, g, tid, a[K], pos, act);
     RFLU_STAMP(p.scratch, K, 2, g, tid);
-    const MidOut<T> o = step_mid<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.r0, g, tid, pos, act);
+    if (mine) {  // this thread owns the workgroup's candidate row: hand out columns K..NB-1
+        if (p.G == 1) {
+#pragma unroll
+            for (int j = K; j < NB; ++j) {
+                T v = a[j];
+                asm volatile("" : "+v"(v));  // keep hipcc from fusing the copies into a memcpy out of a scratch-resident a[]
+                sh->prow[j] = v;
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(p.scratch);
+            const unsigned roff = (unsigned)(K & 1) * PS_BUF_BYTES + PS_HDR_REGION + (unsigned)g * PS_ROW_BYTES;
+            const unsigned tag = p.epoch + (unsigned)K;
+#pragma unroll
+            for (int j = K; j < NB; ++j) Gran<T>::store(rs, roff + j * PS_VAL_BYTES, tag, a[j]);
+        }
+    }
+    const MidOut<T> o = step_b<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.r0, g, tid, pos, act);
     RFLU_STAMP(p.scratch, K, 5, g, tid);
     pos = o.pos;
     act = (o.flags & 2u) != 0;
@@ -518,11 +557,11 @@ __device__ __forceinline__ void pivot_step(const PanelArgs<T>& p, PivotLds<T>* s
 template <typename T, int K0, int K1>
 struct PivotSteps {
     static __device__ __forceinline__ void run(const PanelArgs<T>& p, PivotLds<T>* sh, T (&a)[NB], unsigned& pos,
-                                               bool& act, bool& dead, int g, int tid, int lane, int wave)
+                                               bool& act, bool& dead, int g, int tid)
     {
         if constexpr (K0 < K1) {
-            pivot_step<T, K0>(p, sh, a, pos, act, dead, g, tid, lane, wave);
-            PivotSteps<T, K0 + 1, K1>::run(p, sh, a, pos, act, dead, g, tid, lane, wave);
+            pivot_step<T, K0>(p, sh, a, pos, act, dead, g, tid);
+            PivotSteps<T, K0 + 1, K1>::run(p, sh, a, pos, act, dead, g, tid);
         }
     }
 };
@@ -547,7 +586,7 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_kernel(PanelArgs<T>
     load_rows<T, 1>(p.R, p.ld, row_base, p.m, p.c0, w, a, sh->tile, wave, lane);
 
     bool dead = false;  // set (workgroup-uniformly) after a timeout: skip the remaining steps quickly
-    PivotSteps<T, 0, NB>::run(p, sh, a[0], pos, act, dead, g, tid, lane, wave);
+    PivotSteps<T, 0, NB>::run(p, sh, a[0], pos, act, dead, g, tid);
 
     unsigned posv[1] = {pos};
     store_rows<T, 1>(p.R, p.ld, p.c0, w, a, posv, sh->tile, sh->spos, wave, lane);

@@ -9,7 +9,7 @@ lib.rflu_debug_panel_trace.restype = ctypes.c_int
 lib.rflu_debug_panel_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 h = _ffi.Handle(0); h.set_stream(None)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
-names = ["front", "dump", "barrier1", "exchange", "mid-tail", "update", "step total"]
+names = ["a:front+bar", "a:combine+hdr", "rowpub+poll+reduce", "rowfetch+bar2", "b:tail", "update", "step total"]
 for m in [int(x) for x in (sys.argv[1:] or ["256", "2048", "16384"])]:
     A0 = torch.rand((m, 64), dtype=torch.float64, device="cuda"); ip = torch.zeros(m, dtype=torch.int64, device="cuda"); info = ctypes.c_int64(0)
     for _ in range(3):

@@ -53,27 +53,48 @@ int ensure_bookkeeping(Handle* h, int64_t rows)
     if (h->pm_cnt) RFLU_HIP(hipFree(h->pm_cnt));
     if (h->pm_dst) RFLU_HIP(hipFree(h->pm_dst));
     if (h->pm_src) RFLU_HIP(hipFree(h->pm_src));
+    if (h->linv) RFLU_HIP(hipFree(h->linv));
+    h->linv = nullptr;
     h->pm_cnt = h->pm_dst = h->pm_src = nullptr;
     h->pm_chunks = 0;
     RFLU_HIP(hipMalloc((void**)&h->pm_cnt, (size_t)chunks * sizeof(int)));
     RFLU_HIP(hipMalloc((void**)&h->pm_dst, (size_t)chunks * 2 * NB * sizeof(int)));
     RFLU_HIP(hipMalloc((void**)&h->pm_src, (size_t)chunks * 2 * NB * sizeof(int)));
+    RFLU_HIP(hipMalloc(&h->linv, (size_t)chunks * NB * NB * sizeof(double)));
     RFLU_HIP(hipMemset(h->pm_cnt, 0, (size_t)chunks * sizeof(int)));
     h->pm_chunks = chunks;
     return RFLU_OK;
 }
 
 // ---- B <- L^-1 B by recursive splitting on 64-row boundaries (off-diagonal work = MFMA GEMM) -----------------------
+// linv: inverses of L's 64x64 diagonal blocks (one 64x64 dense block per 64 rows), or nullptr.  With them, triangles of
+// up to 256 rows are solved by ONE fused strip kernel instead of 7 dependent launches.
+constexpr int64_t TRSM_FUSED_MAX = 256;
+
 template <typename T>
-static int trsm_rec(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t ldl, T* B, int64_t ldb)
+static int trsm_rec(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t ldl, T* B, int64_t ldb, const T* linv)
 {
     if (n <= 0 || nrhs <= 0) return RFLU_OK;
+    if (linv && n <= TRSM_FUSED_MAX) return launch_trsm_fused<T>(h, n, nrhs, L, ldl, linv, B, ldb);
     if (n <= NB) return launch_trsm_base<T>(h, n, nrhs, L, ldl, B, ldb);
     const int64_t leaves = (n + NB - 1) / NB;
     const int64_t n1 = ((leaves + 1) / 2) * NB;
-    RFLU_TRY(trsm_rec<T>(h, n1, nrhs, L, ldl, B, ldb));
+    RFLU_TRY(trsm_rec<T>(h, n1, nrhs, L, ldl, B, ldb, linv));
     RFLU_TRY(launch_gemm<T>(h, n - n1, nrhs, n1, L + n1 * ldl, ldl, B, ldb, B + n1 * ldb, ldb));
-    return trsm_rec<T>(h, n - n1, nrhs, L + n1 * ldl + n1, ldl, B + n1 * ldb, ldb);
+    return trsm_rec<T>(h, n - n1, nrhs, L + n1 * ldl + n1, ldl, B + n1 * ldb, ldb,
+                       linv ? linv + (n1 / NB) * NB * NB : nullptr);
+}
+
+// stand-alone TRSM (C ABI building block): invert the diagonal blocks first, then the fused path
+template <typename T>
+static int trsm_public(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t ldl, T* B, int64_t ldb)
+{
+    if (n <= 0 || nrhs <= 0) return RFLU_OK;
+    const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB * sizeof(T);
+    RFLU_TRY(ensure_buffer(&h->linv_tmp, &h->linv_tmp_bytes, need));
+    T* li = static_cast<T*>(h->linv_tmp);
+    RFLU_TRY(launch_diag_inv<T>(h, n, L, ldl, li));
+    return trsm_rec<T>(h, n, nrhs, L, ldl, B, ldb, li);
 }
 
 template <typename T>
@@ -84,11 +105,14 @@ struct Fact {
     int64_t* ipiv;
     int pivot;
 
+    T* linv_at(int64_t row) const { return static_cast<T*>(h->linv) + (row / NB) * NB * NB; }
+
     // leaf: rows [c0, m), columns [c0, c0+w): cooperative panel + the interchanges on every other column
     int leaf(int64_t c0, int64_t w)
     {
         RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, ipiv, pivot));
         if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, 0, c0, c0 + w, n - (c0 + w), c0 / NB, c0 / NB + 1));
+        RFLU_TRY(launch_diag_inv<T>(h, w, R + c0 * ld + c0, ld, linv_at(c0)));  // for the fused TRSMs that follow
         return RFLU_OK;
     }
 
@@ -106,7 +130,7 @@ struct Fact {
         T* A12 = R + c0 * ld + cm;
         T* A21 = R + cm * ld + c0;
         T* A22 = R + cm * ld + cm;
-        RFLU_TRY(trsm_rec<T>(h, n1, c1 - cm, A11, ld, A12, ld));                        // src/lu.jl:235
+        RFLU_TRY(trsm_rec<T>(h, n1, c1 - cm, A11, ld, A12, ld, linv_at(c0)));           // src/lu.jl:235
         RFLU_TRY(launch_gemm<T>(h, m - cm, c1 - cm, n1, A21, ld, A12, ld, A22, ld));    // src/lu.jl:240
         return rec(cm, c1);
     }
@@ -145,14 +169,14 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             RFLU_TRY(f.rec(j, j + jb));
             const int64_t je = j + jb;
             if (je < mn) {  // trailing update of the remaining square part
-                RFLU_TRY(trsm_rec<T>(h, jb, mn - je, R + j * ld + j, ld, R + j * ld + je, ld));
+                RFLU_TRY(trsm_rec<T>(h, jb, mn - je, R + j * ld + j, ld, R + j * ld + je, ld, f.linv_at(j)));
                 RFLU_TRY(launch_gemm<T>(h, m - je, mn - je, jb, R + je * ld + j, ld, R + j * ld + je, ld,
                                         R + je * ld + je, ld));
             }
         }
     }
     if (m < n)  // fat matrix: AR <- L^-1 AR (src/lu.jl:148-154; the interchanges already reached these columns)
-        RFLU_TRY(trsm_rec<T>(h, m, n - m, R, ld, R + m, ld));
+        RFLU_TRY(trsm_rec<T>(h, m, n - m, R, ld, R + m, ld, f.linv_at(0)));
 
     RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     RFLU_HIP(hipStreamSynchronize(h->stream));
@@ -287,6 +311,8 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->pm_cnt) (void)hipFree(h->pm_cnt);
     if (h->pm_dst) (void)hipFree(h->pm_dst);
     if (h->pm_src) (void)hipFree(h->pm_src);
+    if (h->linv) (void)hipFree(h->linv);
+    if (h->linv_tmp) (void)hipFree(h->linv_tmp);
     if (h->pscratch) (void)hipFree(h->pscratch);
     if (h->info_dev) (void)hipFree(h->info_dev);
     if (h->info_pinned) (void)hipHostFree(h->info_pinned);
@@ -346,13 +372,16 @@ int rflu_last_path(rflu_handle_t handle) { return handle ? H(handle)->last_path 
         for (int64_t j = 0; j < w; j += NB) {                                                                         \
             const int64_t jb = std::min<int64_t>(NB, w - j);                                                          \
             if (j > 0) {                                                                                              \
-                RFLU_TRY(trsm_rec<T>(h, j, jb, R + r0 * ld + c0, ld, R + r0 * ld + c0 + j, ld));                      \
+                RFLU_TRY(trsm_rec<T>(h, j, jb, R + r0 * ld + c0, ld, R + r0 * ld + c0 + j, ld,                        \
+                                     static_cast<T*>(h->linv) + (r0 / NB) * NB * NB));                                \
                 RFLU_TRY(launch_gemm<T>(h, m - r0 - j, jb, j, R + (r0 + j) * ld + c0, ld, R + r0 * ld + c0 + j, ld,   \
                                         R + (r0 + j) * ld + c0 + j, ld));                                             \
             }                                                                                                         \
             RFLU_TRY(launch_panel<T>(h, R, ld, m, r0 + j, c0 + j, jb, ipiv, pivot));                                  \
             if (pivot)                                                                                                \
                 RFLU_TRY(launch_laswp2<T>(h, R, ld, c0, j, c0 + j + jb, w - j - jb, (r0 + j) / NB, (r0 + j) / NB + 1)); \
+            RFLU_TRY(launch_diag_inv<T>(h, jb, R + (r0 + j) * ld + c0 + j, ld,                                        \
+                                        static_cast<T*>(h->linv) + ((r0 + j) / NB) * NB * NB));                       \
         }                                                                                                             \
         RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); \
         RFLU_HIP(hipStreamSynchronize(h->stream));                                                                    \
@@ -373,7 +402,7 @@ int rflu_last_path(rflu_handle_t handle) { return handle ? H(handle)->last_path 
                                  int64_t ldb)                                                                         \
     {                                                                                                                 \
         CHECK_HANDLE(handle);                                                                                         \
-        return trsm_rec<T>(H(handle), n, nrhs, L, ldl, B, ldb);                                                       \
+        return trsm_public<T>(H(handle), n, nrhs, L, ldl, B, ldb);                                                       \
     }                                                                                                                 \
     int rflu_gemm_rm_##SFX##_dev(rflu_handle_t handle, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda,      \
                                  const T* B, int64_t ldb, T* C, int64_t ldc)                                          \

@@ -61,6 +61,9 @@ struct Handle {
     int* pm_dst = nullptr;
     int* pm_src = nullptr;
     int64_t pm_chunks = 0;
+    void* linv = nullptr;        // inverses of the 64x64 diagonal blocks of L, one per leaf (pm_chunks x 64 x 64 elements)
+    void* linv_tmp = nullptr;    // same for stand-alone rflu_trsm_rm_* calls
+    size_t linv_tmp_bytes = 0;
 
     // cooperative panel scratch: double-buffered granule records + status words
     unsigned long long* pscratch = nullptr;
@@ -104,6 +107,11 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
                 int64_t ldc);
 template <typename T>
 int launch_trsm_base(Handle* h, int64_t nb, int64_t nrhs, const T* L, int64_t ldl, T* B, int64_t ldb);
+// fused strip TRSM (n <= 256) on pre-inverted 64x64 diagonal blocks, and the batched inversion of those blocks
+template <typename T>
+int launch_trsm_fused(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t ldl, const T* Linv, T* B, int64_t ldb);
+template <typename T>
+int launch_diag_inv(Handle* h, int64_t n, const T* L, int64_t ldl, T* Linv);
 template <typename T>
 int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t chunk0, int64_t chunk1);
 // apply chunks [chunk0, chunk1) to two column ranges at once: [c0, c0+ncolsA) and [c1, c1+ncolsB)

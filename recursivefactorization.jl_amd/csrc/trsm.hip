@@ -82,4 +82,168 @@ int launch_trsm_base(Handle* h, int64_t nb, int64_t nrhs, const T* L, int64_t ld
 template int launch_trsm_base<double>(Handle*, int64_t, int64_t, const double*, int64_t, double*, int64_t);
 template int launch_trsm_base<float>(Handle*, int64_t, int64_t, const float*, int64_t, float*, int64_t);
 
+
+// =====================================================================================================================
+// Fused strip TRSM for triangles of up to 256 rows:  B <- L^-1 B  in ONE launch.
+//
+// The recursive splitting in driver.cpp (trsm_rec) turns a 256-row triangle into 4 base solves + 3 GEMMs = 7 dependent
+// launches of ~20 us each (all latency, no work).  Here one workgroup owns a strip of 32 right-hand-side columns and
+// walks the 64-row blocks top to bottom (left-looking):
+//     acc   = B_d - sum_{e<d} L_de * X_e          MFMA, A fragments straight from global/L2, X_e from LDS
+//     X_d   = inv(L_dd) * acc                     MFMA with the pre-inverted 64x64 diagonal block (diag_inv_kernel)
+// The inverse of a unit lower triangular block with |l_ij| <= 1 (partial pivoting) is what MAGMA/rocBLAS-style TRSMs
+// use for their diagonal blocks as well; the off-diagonal 90+ % of the flops are plain GEMM.
+// Geometry: 256 threads = 4 waves; wave w owns rows [16w,16w+16) of the 64-row block x 32 columns = 2 MFMA fragments.
+// LDS: up to 4 solved blocks X_e as MFMA B operands, [64][48] each (row stride 48 == 16 mod 32 -> conflict-free reads).
+// =====================================================================================================================
+constexpr int TF_MAXN = 256;
+constexpr int TF_COLS = 32;
+constexpr int TF_XLD = TF_COLS + 16;
+
+template <typename T>
+struct MfmaT;
+template <>
+struct MfmaT<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct MfmaT<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) trsm_fused_kernel(int n, int64_t nrhs, const T* __restrict__ L, int64_t ldl,
+                                                         const T* __restrict__ Linv, T* __restrict__ B, int64_t ldb)
+{
+    typedef typename MfmaT<T>::acc_t acc_t;
+    __shared__ T Xs[(TF_MAXN / NB) * NB * TF_XLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t col0 = (int64_t)blockIdx.x * TF_COLS;
+    const int nblk = (n + NB - 1) / NB;
+    const int fi = lane & 15, fk = lane >> 4;      // A fragment: row fi, k-offset fk ; B fragment: k-offset fk, col fi
+    const int arow = wave * 16 + fi;               // row of this lane's A fragment inside the 64-row block
+
+    for (int d = 0; d < nblk; ++d) {
+        const int rows_d = min(NB, n - d * NB);
+        // ---- acc = B_d (C-fragment layout: row = wave*16 + crow(lane,r), col = t*16 + fi) ----
+        acc_t acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 16 + MfmaT<T>::crow(lane, r);
+                const int64_t col = col0 + t * 16 + fi;
+                acc[t][r] = (row < rows_d && col < nrhs) ? B[(int64_t)(d * NB + row) * ldb + col] : T(0);
+            }
+        // ---- acc -= L_de * X_e ----
+        for (int e = 0; e < d; ++e) {
+            T a[16];
+            const T* Lp = L + (int64_t)(d * NB + arow) * ldl + e * NB + fk;
+            const bool rok = arow < rows_d;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) a[kk] = rok ? -Lp[kk * 4] : T(0);
+            const T* Xe = Xs + e * NB * TF_XLD;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const T b0 = Xe[(kk * 4 + fk) * TF_XLD + fi];
+                const T b1 = Xe[(kk * 4 + fk) * TF_XLD + 16 + fi];
+                acc[0] = MfmaT<T>::run(a[kk], b0, acc[0]);
+                acc[1] = MfmaT<T>::run(a[kk], b1, acc[1]);
+            }
+        }
+        // ---- stage acc as a B operand, then X_d = inv(L_dd) * acc ----
+        T* Xd = Xs + d * NB * TF_XLD;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xd[(wave * 16 + MfmaT<T>::crow(lane, r)) * TF_XLD + t * 16 + fi] = acc[t][r];
+        T ai[16];
+        {
+            const T* Ip = Linv + (int64_t)d * NB * NB + arow * NB + fk;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) ai[kk] = Ip[kk * 4];
+        }
+        __syncthreads();
+        acc_t x[2] = {acc_t{T(0), T(0), T(0), T(0)}, acc_t{T(0), T(0), T(0), T(0)}};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const T b0 = Xd[(kk * 4 + fk) * TF_XLD + fi];
+            const T b1 = Xd[(kk * 4 + fk) * TF_XLD + 16 + fi];
+            x[0] = MfmaT<T>::run(ai[kk], b0, x[0]);
+            x[1] = MfmaT<T>::run(ai[kk], b1, x[1]);
+        }
+        __syncthreads();  // everybody has read the staged acc
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 16 + MfmaT<T>::crow(lane, r);
+                const int64_t col = col0 + t * 16 + fi;
+                Xd[row * TF_XLD + t * 16 + fi] = x[t][r];
+                if (row < rows_d && col < nrhs) B[(int64_t)(d * NB + row) * ldb + col] = x[t][r];
+            }
+        __syncthreads();  // X_d visible to the following block rows
+    }
+}
+
+// inverse of the unit lower triangular nb x nb block at Lblk (row-major, ldl) -> dense 64x64 row-major Linv
+// (unit diagonal explicit, zeros above it and outside nb; identity padding so that partial blocks behave).
+// Batched: block b inverts the diagonal block starting at row/column 64*b of the n x n triangle L.
+template <typename T>
+__global__ void __launch_bounds__(64) diag_inv_kernel(int n, const T* __restrict__ L, int64_t ldl, T* __restrict__ Linv_all)
+{
+    __shared__ T sL[NB * NB];
+    const int j = threadIdx.x;
+    const int b = blockIdx.x;
+    const int nb = min(NB, n - b * NB);
+    const T* Lblk = L + (int64_t)b * NB * ldl + b * NB;
+    T* Linv = Linv_all + (size_t)b * NB * NB;
+    {
+        T tmp[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) tmp[i] = (i < nb && j < i) ? Lblk[(int64_t)i * ldl + j] : T(0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) sL[i * NB + j] = tmp[i];
+    }
+    __syncthreads();
+    T x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) x[i] = (i == j) ? T(1) : T(0);
+    TrsmRow<T, 1>::run(sL, x);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) Linv[i * NB + j] = x[i];
+}
+
+// invert every 64x64 diagonal block of the n x n unit lower triangle L into Linv[0 .. ceil(n/64))
+template <typename T>
+int launch_diag_inv(Handle* h, int64_t n, const T* L, int64_t ldl, T* Linv)
+{
+    if (n <= 0) return RFLU_OK;
+    ProfScope ps(h, RFLU_K_TRSM, (double)n * NB * NB / 3.0);
+    hipLaunchKernelGGL(diag_inv_kernel<T>, dim3((unsigned)((n + NB - 1) / NB)), dim3(64), 0, h->stream, (int)n, L, ldl, Linv);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+template <typename T>
+int launch_trsm_fused(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t ldl, const T* Linv, T* B, int64_t ldb)
+{
+    if (n <= 0 || nrhs <= 0) return RFLU_OK;
+    if (n > TF_MAXN) { set_error("launch_trsm_fused: %lld rows exceed %d", (long long)n, TF_MAXN); return RFLU_ERR_ARG; }
+    ProfScope ps(h, RFLU_K_TRSM, (double)n * (double)n * (double)nrhs);
+    const unsigned grid = (unsigned)((nrhs + TF_COLS - 1) / TF_COLS);
+    hipLaunchKernelGGL(trsm_fused_kernel<T>, dim3(grid), dim3(256), 0, h->stream, (int)n, nrhs, L, ldl, Linv, B, ldb);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+template int launch_diag_inv<double>(Handle*, int64_t, const double*, int64_t, double*);
+template int launch_diag_inv<float>(Handle*, int64_t, const float*, int64_t, float*);
+template int launch_trsm_fused<double>(Handle*, int64_t, int64_t, const double*, int64_t, const double*, double*, int64_t);
+template int launch_trsm_fused<float>(Handle*, int64_t, int64_t, const float*, int64_t, const float*, float*, int64_t);
+
 }  // namespace rflu

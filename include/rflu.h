@@ -41,7 +41,7 @@ enum rflu_status {
 
 /* rflu_last_path values: which implementation served the last getrf call on this handle.  The analogue of the
  * reference's dispatch-routing tests (test/runtests.jl:86-114,162-192): tests assert the HIP path really ran. */
-enum rflu_path { RFLU_PATH_NONE = 0, RFLU_PATH_HIP_RECURSIVE = 1, RFLU_PATH_HIP_BLOCKED = 2 };
+enum rflu_path { RFLU_PATH_NONE = 0, RFLU_PATH_HIP_RECURSIVE = 1, RFLU_PATH_HIP_BLOCKED = 2, RFLU_PATH_HIP_LOOKAHEAD = 3 };
 
 /* kernel classes for the built-in per-kernel timers (rflu_profile_*) */
 enum rflu_kclass {
@@ -66,9 +66,12 @@ int rflu_last_path(rflu_handle_t handle);
 
 /* ---- the boundary: lu!(A, ipiv, pivot; blocksize) on HOST buffers (caller-owned, column-major) ----
  * Replaces src/lu.jl:114-126 (recursive path + unblocked fallback) for Float64 / Float32.
- * blocksize: 0 = pure Toledo recursion on the whole matrix (the reference's structure); > 0 = width of the outer
- * right-looking block column, each factored by the same recursion (`blocksize` re-read as the
- * GPU panel width, BASELINE config 3 sweeps 64/128/256).  Rounded up to a multiple of 64. */
+ * blocksize: < 0 = pure Toledo recursion on the whole matrix, one stream (the reference's structure, src/lu.jl:189-263);
+ *            > 0 = width of the outer right-looking block column, each block column factored by the same recursion
+ *                  (`blocksize` re-read as the GPU panel width, BASELINE config 3 sweeps
+ *                  64/128/256; rounded up to a multiple of 64), with one block column of lookahead: the next block
+ *                  column is updated and factored while the rest of the trailing update still runs on a second stream;
+ *            = 0 = library default (pure recursion below 4096 columns, block columns of 1024 with lookahead above). */
 int rflu_getrf_f64(rflu_handle_t handle, int64_t m, int64_t n, double* A_host, int64_t lda, int64_t* ipiv_host,
                    int pivot, int64_t blocksize, int64_t* info);
 int rflu_getrf_f32(rflu_handle_t handle, int64_t m, int64_t n, float* A_host, int64_t lda, int64_t* ipiv_host,

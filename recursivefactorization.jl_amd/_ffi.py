@@ -54,7 +54,7 @@ for _k, _v in _TYPED.items():
 
 K_GEMM, K_TRSM, K_LASWP, K_PANEL, K_TRANSPOSE, K_MISC = range(6)
 KCLASS_NAMES = ["gemm", "trsm", "laswp", "panel", "transpose", "misc"]
-PATH_NONE, PATH_HIP_RECURSIVE, PATH_HIP_BLOCKED = 0, 1, 2
+PATH_NONE, PATH_HIP_RECURSIVE, PATH_HIP_BLOCKED, PATH_HIP_LOOKAHEAD = 0, 1, 2, 3
 
 _lib = None
 

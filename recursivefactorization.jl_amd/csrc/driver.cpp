@@ -104,6 +104,7 @@ struct Fact {
     int64_t ld, m, n;  // full matrix: m rows, n columns
     int64_t* ipiv;
     int pivot;
+    int64_t sw_lo = 0, sw_hi = -1;  // column range that receives a leaf's interchanges right away ([0, n) by default)
 
     T* linv_at(int64_t row) const { return static_cast<T*>(h->linv) + (row / NB) * NB * NB; }
 
@@ -111,7 +112,8 @@ struct Fact {
     int leaf(int64_t c0, int64_t w)
     {
         RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, ipiv, pivot));
-        if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, 0, c0, c0 + w, n - (c0 + w), c0 / NB, c0 / NB + 1));
+        const int64_t hi = sw_hi < 0 ? n : sw_hi;
+        if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, sw_lo, c0 - sw_lo, c0 + w, hi - (c0 + w), c0 / NB, c0 / NB + 1));
         RFLU_TRY(launch_diag_inv<T>(h, w, R + c0 * ld + c0, ld, linv_at(c0)));  // for the fused TRSMs that follow
         return RFLU_OK;
     }
@@ -136,7 +138,115 @@ struct Fact {
     }
 };
 
-// Factor the row-major m x n matrix R in place.  blocksize <= 0: pure recursion; else right-looking over block columns.
+static int get_event(Handle* h, size_t idx, hipEvent_t* ev)
+{
+    while (h->events.size() <= idx) {
+        hipEvent_t e;
+        RFLU_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->events.push_back(e);
+    }
+    *ev = h->events[idx];
+    return RFLU_OK;
+}
+
+// The update stream leaves `reserve` CUs (a multiple of 32) to the critical-path stream so that the cooperative panel
+// kernel (one 512-thread workgroup per CU) finds all its workgroups a home at once.
+static int ensure_ustream(Handle* h, int reserve)
+{
+    if (h->ustream && h->ustream_reserve == reserve) return RFLU_OK;
+    if (h->ustream) { RFLU_HIP(hipStreamSynchronize(h->ustream)); RFLU_HIP(hipStreamDestroy(h->ustream)); h->ustream = nullptr; }
+    // CU mask bits are enumerated round-robin over the 8 XCDs (scripts/probes/cumask.hip): bits 0..31 are 4 CUs of every
+    // XCD, and so on.  A mask that empties an XCD is ignored by the runtime, so whole 32-bit words are cleared.
+    uint32_t mask[8];
+    for (int i = 0; i < 8; ++i) mask[i] = (i < reserve / 32) ? 0u : 0xffffffffu;
+    if (hipExtStreamCreateWithCUMask(&h->ustream, 8, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        RFLU_HIP(hipStreamCreateWithFlags(&h->ustream, hipStreamNonBlocking));
+    }
+    h->ustream_reserve = reserve;
+    return RFLU_OK;
+}
+
+// Right-looking over block columns of width W with one block column of lookahead (two streams).
+//   P (h->stream, all CUs): panel_b -> evP[b] -> [wait evU1[b-1]] next_b (update of block column b+1) -> panel_{b+1} ...
+//   U (h->ustream, 224 CUs): [wait evP[b]] left swaps_b -> rest_b.part1 (block column b+2) -> evU1[b] -> rest_b.part2
+// Every block column receives the same operations in the same order as in the recursion; only independent pieces
+// overlap in time, so the factors are those of the one-stream path.
+template <typename T>
+static int factor_lookahead(Fact<T>& f, int64_t W)
+{
+    Handle* h = f.h;
+    {
+        const int64_t wgs = (f.m + PANEL_THREADS - 1) / PANEL_THREADS;  // workgroups of the tallest panel
+        RFLU_TRY(ensure_ustream(h, wgs <= 32 ? 32 : (wgs <= 64 ? 64 : 128)));
+    }
+    hipStream_t P = h->stream, U = h->ustream;
+    const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
+    T* R = f.R;
+    const int64_t nblk = (mn + W - 1) / W;
+    hipEvent_t ev;
+    // U must not start before everything already queued on P (layout change, info reset) is done
+    RFLU_TRY(get_event(h, 0, &ev));
+    RFLU_HIP(hipEventRecord(ev, P));
+    RFLU_HIP(hipStreamWaitEvent(U, ev, 0));
+
+    auto update = [&](hipStream_t st, int64_t j0, int64_t jb, int64_t c0, int64_t c1) -> int {
+        // apply block column [j0, j0+jb) to columns [c0, c1): interchanges, block-row solve, Schur update
+        if (c1 <= c0) return RFLU_OK;
+        hipStream_t saved = h->stream;
+        h->stream = st;
+        int rc = RFLU_OK;
+        const int64_t je = j0 + jb;
+        if (f.pivot) rc = launch_laswp<T>(h, R, ld, c0, c1 - c0, j0 / NB, (je + NB - 1) / NB);
+        if (rc == RFLU_OK) rc = trsm_rec<T>(h, jb, c1 - c0, R + j0 * ld + j0, ld, R + j0 * ld + c0, ld, f.linv_at(j0));
+        if (rc == RFLU_OK && m > je)
+            rc = launch_gemm<T>(h, m - je, c1 - c0, jb, R + je * ld + j0, ld, R + j0 * ld + c0, ld, R + je * ld + c0, ld);
+        h->stream = saved;
+        return rc;
+    };
+
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
+        // ---- panel b on P: Toledo recursion on the block column, interchanges confined to its own columns ----
+        f.sw_lo = j0;
+        f.sw_hi = je;
+        RFLU_TRY(f.rec(j0, je));
+        RFLU_TRY(get_event(h, 1 + 2 * b, &ev));
+        RFLU_HIP(hipEventRecord(ev, P));
+        RFLU_HIP(hipStreamWaitEvent(U, ev, 0));
+        // ---- U: interchanges on the finished columns to the left ----
+        if (f.pivot && j0 > 0) {
+            hipStream_t saved = h->stream;
+            h->stream = U;
+            const int rc = launch_laswp<T>(h, R, ld, 0, j0, j0 / NB, (je + NB - 1) / NB);
+            h->stream = saved;
+            RFLU_TRY(rc);
+        }
+        if (je >= n) break;
+        const int64_t n1e = std::min(je + W, n);                                            // end of block column b+1
+        const int64_t n2e = std::min(n1e + W, n);                                           // end of block column b+2
+        // ---- P: next block column (needs rest_{b-1}.part1, which updated exactly these columns) ----
+        if (b > 0) {
+            RFLU_TRY(get_event(h, 2 + 2 * (b - 1), &ev));
+            RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
+        }
+        RFLU_TRY(update(P, j0, jb, je, n1e));
+        // ---- U: block column b+2 first (the next `next`), then everything further right ----
+        RFLU_TRY(update(U, j0, jb, n1e, n2e));
+        RFLU_TRY(get_event(h, 2 + 2 * b, &ev));
+        RFLU_HIP(hipEventRecord(ev, U));
+        RFLU_TRY(update(U, j0, jb, n2e, n));
+    }
+    f.sw_lo = 0;
+    f.sw_hi = -1;
+    // join: P continues only after U has drained
+    RFLU_TRY(get_event(h, 0, &ev));
+    RFLU_HIP(hipEventRecord(ev, U));
+    RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
+    return RFLU_OK;
+}
+
+// Factor the row-major m x n matrix R in place (see rflu.h for `blocksize`).
 template <typename T>
 static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* ipiv, int pivot, int64_t blocksize,
                     int64_t* info)
@@ -158,9 +268,15 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     if (!pivot && ipiv) RFLU_TRY(launch_iota_ipiv(h, ipiv, 0, mn));  // src/lu.jl:111-113
 
     Fact<T> f{h, R, ld, m, n, ipiv, pivot};
-    if (blocksize <= 0 || blocksize >= mn) {
+    bool fat_tail_done = false;
+    if (blocksize == 0) blocksize = (mn >= 4096) ? 1024 : -1;
+    if (blocksize < 0 || blocksize >= mn) {
         h->last_path = RFLU_PATH_HIP_RECURSIVE;
         RFLU_TRY(f.rec(0, mn));
+    } else if (!h->prof) {
+        h->last_path = RFLU_PATH_HIP_LOOKAHEAD;
+        RFLU_TRY(factor_lookahead<T>(f, round_up(blocksize, NB)));
+        fat_tail_done = true;  // the block-column updates already reached the columns right of the square part
     } else {
         h->last_path = RFLU_PATH_HIP_BLOCKED;
         const int64_t bs = round_up(blocksize, NB);
@@ -175,7 +291,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             }
         }
     }
-    if (m < n)  // fat matrix: AR <- L^-1 AR (src/lu.jl:148-154; the interchanges already reached these columns)
+    if (m < n && !fat_tail_done)  // fat matrix: AR <- L^-1 AR (src/lu.jl:148-154; interchanges already applied there)
         RFLU_TRY(trsm_rec<T>(h, m, n - m, R, ld, R + m, ld, f.linv_at(0)));
 
     RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
@@ -318,6 +434,8 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->info_pinned) (void)hipHostFree(h->info_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ustream) (void)hipStreamDestroy(h->ustream);
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return RFLU_OK;

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/rflu.h"
 
 namespace rflu {
@@ -45,6 +47,11 @@ struct Handle {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // second stream for the lookahead driver: the deferred trailing updates run here, restricted by a CU mask to
+    // 224 of the 256 CUs so that the cooperative panel kernels of the critical path always find 32 free CUs
+    hipStream_t ustream = nullptr;
+    int ustream_reserve = 0;
+    std::vector<hipEvent_t> events;   // reusable, timing disabled
     int last_path = RFLU_PATH_NONE;
     int num_cus = 256;
 

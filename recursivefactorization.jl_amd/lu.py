@@ -15,8 +15,9 @@ Same names, argument meaning and error behaviour; Julia's ``!`` is spelled ``_``
     recursive/unblocked crossover, :90,114) is accepted and ignored, and there is NO CPU fallback: other element types
     raise ``TypeError`` (the Julia glue in INTEGRATION.md keeps the reference's own CPU code for those);
   * ``thread`` is accepted and ignored (the GPU path has no thread flag);
-  * ``blocksize``: ``None``/0 = pure Toledo recursion; 64/128/256... = width of the outer right-looking block column
-    (include/rflu.h).
+  * ``blocksize``: ``None``/0 = library default (pure Toledo recursion below 4096 columns, 1024-wide block columns with
+    one block column of lookahead above); negative = pure recursion; 64/128/256... = width of the outer right-looking
+    block column (include/rflu.h).
 
 Inputs: a NumPy array (host; staged through HBM by ``rflu_getrf_*``) or a ``torch`` tensor on the GPU
 (column-major view, i.e. ``stride(0) == 1``, -> ``rflu_getrf_*_dev``; C-contiguous -> ``rflu_getrf_rm_*_dev``).
@@ -253,4 +254,4 @@ def lu(A, pivot=True, thread=False, **kwargs) -> LU:
 
 def last_path(device: int = 0) -> str:
     """Which implementation served the last factorization on ``device`` ("hip-recursive" / "hip-blocked" / "none")."""
-    return {0: "none", 1: "hip-recursive", 2: "hip-blocked"}[_ffi.default_handle(device).last_path()]
+    return {0: "none", 1: "hip-recursive", 2: "hip-blocked", 3: "hip-lookahead"}[_ffi.default_handle(device).last_path()]

@@ -32,7 +32,10 @@ def check_against_oracle(A, F, pivot=True, factor_tol_mult=50):
         bound = tol_E(A) if pivot else 10 * np.sqrt(tol_E(A)) * max(1.0, float(np.max(np.abs(Fo))))
         assert mx < bound
         scale = max(1.0, float(np.max(np.abs(Fo))))
-        assert np.max(np.abs(lu_host - Fo)) < factor_tol_mult * tol_E(A) * scale
+        # pivoted: backward-stable, factors agree to a small multiple of E; unpivoted LU is not (the reference itself only
+        # asks 10*sqrt(E) of it, runtests.jl:20), so two correct summation orders may differ by that much
+        ftol = factor_tol_mult * tol_E(A) if pivot else 10 * np.sqrt(tol_E(A))
+        assert np.max(np.abs(lu_host - Fo)) < ftol * scale
     return lu_host, ip
 
 
@@ -103,11 +106,26 @@ def test_lu_tall_and_fat(shape):
 
 
 @pytest.mark.parametrize("blocksize", [64, 128, 256])
-def test_blocked_right_looking_variant_gives_same_pivots(blocksize):
+def test_blocked_lookahead_variant_gives_same_pivots(blocksize):
+    # BASELINE config 3's block-size sweep: right-looking block columns + one block column of lookahead on two streams
     A = rand_matrix(1000, 1000, seed=10)
     F = rf.lu(A, True, check=False, blocksize=blocksize)
-    assert rf.last_path() == "hip-blocked"
+    assert rf.last_path() == "hip-lookahead"
     check_against_oracle(A, F)
+    G = rf.lu(A, True, check=False, blocksize=-1)
+    assert rf.last_path() == "hip-recursive"
+    assert np.array_equal(G.ipiv, F.ipiv)
+
+
+@pytest.mark.parametrize("shape,blocksize", [((900, 1300), 256), ((1300, 900), 256), ((2048, 2048), 512), ((700, 700), 128)])
+def test_lookahead_shapes(shape, blocksize):
+    A = rand_matrix(shape[0], shape[1], seed=31)
+    F = rf.lu(A, True, check=False, blocksize=blocksize)
+    assert rf.last_path() == "hip-lookahead"
+    check_against_oracle(A, F)
+    N = (rand_matrix(shape[0], shape[1], seed=32) + 10 * np.eye(*shape)).astype(np.float64, order="F")
+    Fn = rf.lu(N, rf.NoPivot(), check=False, blocksize=blocksize)
+    check_against_oracle(N, rf.LU(Fn.factors, np.arange(1, min(shape) + 1), Fn.info), pivot=False)
 
 
 def test_row_major_device_entry():

@@ -14,6 +14,7 @@
 //     :256-260) and info is the global index of the first zero pivot (the reference's offset fix-up :248-255).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -113,8 +114,10 @@ struct Fact {
     {
         RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, ipiv, pivot));
         const int64_t hi = sw_hi < 0 ? n : sw_hi;
-        if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, sw_lo, c0 - sw_lo, c0 + w, hi - (c0 + w), c0 / NB, c0 / NB + 1));
-        RFLU_TRY(launch_diag_inv<T>(h, w, R + c0 * ld + c0, ld, linv_at(c0)));  // for the fused TRSMs that follow
+        // one launch: the leaf's interchanges on the other columns + the inverse of its diagonal block (fused TRSMs)
+        if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, sw_lo, c0 - sw_lo, c0 + w, hi - (c0 + w), c0 / NB, c0 / NB + 1, w,
+                                             R + c0 * ld + c0, linv_at(c0)));
+        else RFLU_TRY(launch_diag_inv<T>(h, w, R + c0 * ld + c0, ld, linv_at(c0)));
         return RFLU_OK;
     }
 
@@ -178,7 +181,12 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
     Handle* h = f.h;
     {
         const int64_t wgs = (f.m + PANEL_THREADS - 1) / PANEL_THREADS;  // workgroups of the tallest panel
-        RFLU_TRY(ensure_ustream(h, wgs <= 32 ? 32 : (wgs <= 64 ? 64 : 128)));
+        int reserve = wgs <= 32 ? 32 : (wgs <= 64 ? 64 : 128);
+        if (const char* e = getenv("RFLU_RESERVE_CUS")) {  // tuning knob: CUs kept away from the update stream
+            const int v = atoi(e);
+            if (v >= 32 && v <= 224 && v % 32 == 0) reserve = v;
+        }
+        RFLU_TRY(ensure_ustream(h, reserve));
     }
     hipStream_t P = h->stream, U = h->ustream;
     const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
@@ -497,9 +505,12 @@ int rflu_last_path(rflu_handle_t handle) { return handle ? H(handle)->last_path 
             }                                                                                                         \
             RFLU_TRY(launch_panel<T>(h, R, ld, m, r0 + j, c0 + j, jb, ipiv, pivot));                                  \
             if (pivot)                                                                                                \
-                RFLU_TRY(launch_laswp2<T>(h, R, ld, c0, j, c0 + j + jb, w - j - jb, (r0 + j) / NB, (r0 + j) / NB + 1)); \
-            RFLU_TRY(launch_diag_inv<T>(h, jb, R + (r0 + j) * ld + c0 + j, ld,                                        \
-                                        static_cast<T*>(h->linv) + ((r0 + j) / NB) * NB * NB));                       \
+                RFLU_TRY(launch_laswp2<T>(h, R, ld, c0, j, c0 + j + jb, w - j - jb, (r0 + j) / NB, (r0 + j) / NB + 1,   \
+                                          jb, R + (r0 + j) * ld + c0 + j,                                             \
+                                          static_cast<T*>(h->linv) + ((r0 + j) / NB) * NB * NB));                     \
+            else                                                                                                      \
+                RFLU_TRY(launch_diag_inv<T>(h, jb, R + (r0 + j) * ld + c0 + j, ld,                                    \
+                                            static_cast<T*>(h->linv) + ((r0 + j) / NB) * NB * NB));                   \
         }                                                                                                             \
         RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); \
         RFLU_HIP(hipStreamSynchronize(h->stream));                                                                    \

@@ -8,21 +8,31 @@
 // costs exactly its algorithmic 4*sizeof(T) bytes per column of HBM traffic -- no cache-line amplification.
 // Roofline: HBM (8 TB/s spec, ~6.3 TB/s achievable); algorithmic bytes per launch = 4*sizeof(T)*ncols*pivots.
 #include "rflu_internal.hpp"
+#include "trsm_row.hpp"
 
 namespace rflu {
 
 constexpr int LW_COLS = 64;           // columns per workgroup (one lane per column)
 constexpr int LW_ROWS_PER_THREAD = (2 * NB) / 4;  // 4 waves share the <=128 moves of a chunk
 
+// inv_nb > 0: one extra workgroup (the last) inverts the leaf's 64x64 diagonal block for the fused TRSMs that follow
+// (trsm.hip) -- it rides along with the leaf's interchange launch instead of costing a dependent launch of its own.
 template <typename T>
 __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA,
                                                     int64_t c1, int64_t ncolsB, const int* __restrict__ pm_cnt,
                                                     const int* __restrict__ pm_dst, const int* __restrict__ pm_src,
-                                                    int chunk0, int chunk1)
+                                                    int chunk0, int chunk1, int inv_nb, const T* inv_L, T* inv_out)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // two column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB) are covered by one launch (left and right of a panel)
+    __shared__ T sL[NB * NB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t blocksA = (ncolsA + LW_COLS - 1) / LW_COLS;
+    const int64_t blocksB = (ncolsB + LW_COLS - 1) / LW_COLS;
+    if ((int64_t)blockIdx.x >= blocksA + blocksB) {
+        if (inv_nb > 0 && threadIdx.x < 64) diag_inv_block<T>(inv_nb, inv_L, ld, inv_out, sL, lane);
+        return;
+    }
+    // two column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB) are covered by one launch (left and right of a panel)
     int64_t col;
     bool active;
     if ((int64_t)blockIdx.x < blocksA) {
@@ -36,37 +46,44 @@ __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t l
     }
     T v[LW_ROWS_PER_THREAD];
     for (int t = chunk0; t < chunk1; ++t) {
+        // the whole move list of the chunk in four coalesced loads (lane e holds entries e and e+64) ...
         const int cnt = pm_cnt[t];
-        const int* dst = pm_dst + (size_t)t * 2 * NB;
-        const int* src = pm_src + (size_t)t * 2 * NB;
+        const int s0 = pm_src[(size_t)t * 2 * NB + lane], s1 = pm_src[(size_t)t * 2 * NB + NB + lane];
+        const int d0 = pm_dst[(size_t)t * 2 * NB + lane], d1 = pm_dst[(size_t)t * 2 * NB + NB + lane];
+        // ... so that all row loads of the chunk are in flight together (one memory latency, not one per row)
 #pragma unroll
         for (int i = 0; i < LW_ROWS_PER_THREAD; ++i) {
-            const int e = wave + 4 * i;
-            if (e < cnt && active) v[i] = R[(int64_t)src[e] * ld + col];
+            const int e = wave + 4 * i;  // wave-uniform
+            const int src = (e < NB) ? __builtin_amdgcn_readlane(s0, e & 63) : __builtin_amdgcn_readlane(s1, e & 63);
+            if (e < cnt && active) v[i] = R[(int64_t)src * ld + col];
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < LW_ROWS_PER_THREAD; ++i) {
             const int e = wave + 4 * i;
-            if (e < cnt && active) R[(int64_t)dst[e] * ld + col] = v[i];
+            const int dst = (e < NB) ? __builtin_amdgcn_readlane(d0, e & 63) : __builtin_amdgcn_readlane(d1, e & 63);
+            if (e < cnt && active) R[(int64_t)dst * ld + col] = v[i];
         }
         __syncthreads();
     }
 }
 
-// Apply chunks [chunk0, chunk1) to the column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB).
+// Apply chunks [chunk0, chunk1) to the column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB); optionally invert the
+// inv_nb x inv_nb unit lower block at inv_L (leading dimension ld) into inv_out in the same launch.
 template <typename T>
 int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t chunk0,
-                  int64_t chunk1)
+                  int64_t chunk1, int64_t inv_nb, const T* inv_L, T* inv_out)
 {
     if (ncolsA < 0) ncolsA = 0;
     if (ncolsB < 0) ncolsB = 0;
-    if (chunk1 <= chunk0 || ncolsA + ncolsB == 0) return RFLU_OK;
-    const int64_t blocks = (ncolsA + LW_COLS - 1) / LW_COLS + (ncolsB + LW_COLS - 1) / LW_COLS;
+    const bool swaps = chunk1 > chunk0 && ncolsA + ncolsB > 0;
+    if (!swaps && inv_nb <= 0) return RFLU_OK;
+    if (!swaps) { ncolsA = ncolsB = 0; }
+    const int64_t blocks = (ncolsA + LW_COLS - 1) / LW_COLS + (ncolsB + LW_COLS - 1) / LW_COLS + (inv_nb > 0 ? 1 : 0);
     ProfScope ps(h, RFLU_K_LASWP,
                  4.0 * sizeof(T) * (double)(ncolsA + ncolsB) * (double)NB * (double)(chunk1 - chunk0));
     hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, h->stream, R, ld, c0, ncolsA, c1, ncolsB,
-                       h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk0, (int)chunk1);
+                       h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk0, (int)chunk1, (int)inv_nb, inv_L, inv_out);
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }
@@ -74,13 +91,13 @@ int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64
 template <typename T>
 int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t chunk0, int64_t chunk1)
 {
-    return launch_laswp2<T>(h, R, ld, c0, ncols, 0, 0, chunk0, chunk1);
+    return launch_laswp2<T>(h, R, ld, c0, ncols, 0, 0, chunk0, chunk1, 0, nullptr, nullptr);
 }
 
 template int launch_laswp<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t);
 template int launch_laswp<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t);
-template int launch_laswp2<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
-template int launch_laswp2<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);
+template int launch_laswp2<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, double*);
+template int launch_laswp2<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const float*, float*);
 
 // ---- tiled transpose: out[r][c] = in[c][r]; "rows_out x cols_out" is the shape of `out` seen as row-major ------------
 // Used for column-major <-> R layout: a column-major m x n matrix (lda) IS a row-major n x m matrix (ld = lda).

@@ -124,7 +124,7 @@ int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t
 // apply chunks [chunk0, chunk1) to two column ranges at once: [c0, c0+ncolsA) and [c1, c1+ncolsB)
 template <typename T>
 int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t chunk0,
-                  int64_t chunk1);
+                  int64_t chunk1, int64_t inv_nb = 0, const T* inv_L = nullptr, T* inv_out = nullptr);
 // fold the interchanges ipiv[k0..k1) (k0 a multiple of NB) into per-chunk row-move lists
 int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, int64_t m);
 size_t panel_scratch_bytes();

@@ -11,27 +11,9 @@
 // coalesced along the row (lanes = consecutive columns of a row-major row).
 // Roofline: fp64 vector FMA issue; algorithmic work nb^2 * nrhs flops per launch (a few % of the path's total).
 #include "rflu_internal.hpp"
+#include "trsm_row.hpp"
 
 namespace rflu {
-
-template <typename T, int I>
-struct TrsmRow {
-    static __device__ __forceinline__ void run(const T* sL, T (&x)[NB])
-    {
-        if constexpr (I < NB) {
-            // four independent partial sums: a dependent fp64 FMA chain costs ~10+ cycles per link on one wave/SIMD
-            T acc[4] = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-            for (int k = 0; k < I; ++k) acc[k & 3] += sL[I * NB + k] * x[k];
-            T s = x[I] - ((acc[0] + acc[1]) + (acc[2] + acc[3]));
-            // pin row I's arithmetic before the next row's LDS reads: hipcc otherwise hoists all 2016 reads above the
-            // FMA chains and spills ~14 KB per lane
-            asm volatile("" : "+v"(s) : : "memory");
-            x[I] = s;
-            TrsmRow<T, I + 1>::run(sL, x);
-        }
-    }
-};
 
 template <typename T>
 __global__ void __launch_bounds__(128) trsm_base_kernel(int nb, int64_t nrhs, const T* __restrict__ L, int64_t ldl,
@@ -200,22 +182,7 @@ __global__ void __launch_bounds__(64) diag_inv_kernel(int n, const T* __restrict
     const int j = threadIdx.x;
     const int b = blockIdx.x;
     const int nb = min(NB, n - b * NB);
-    const T* Lblk = L + (int64_t)b * NB * ldl + b * NB;
-    T* Linv = Linv_all + (size_t)b * NB * NB;
-    {
-        T tmp[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) tmp[i] = (i < nb && j < i) ? Lblk[(int64_t)i * ldl + j] : T(0);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) sL[i * NB + j] = tmp[i];
-    }
-    __syncthreads();
-    T x[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) x[i] = (i == j) ? T(1) : T(0);
-    TrsmRow<T, 1>::run(sL, x);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) Linv[i * NB + j] = x[i];
+    diag_inv_block<T>(nb, L + (int64_t)b * NB * ldl + b * NB, ldl, Linv_all + (size_t)b * NB * NB, sL, j);
 }
 
 // invert every 64x64 diagonal block of the n x n unit lower triangle L into Linv[0 .. ceil(n/64))

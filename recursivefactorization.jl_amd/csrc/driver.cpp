@@ -567,7 +567,7 @@ int rflu_debug_panel_trace(rflu_handle_t handle, long long* out512)
     CHECK_HANDLE(handle);
     Handle* h = H(handle);
     RFLU_HIP(hipStreamSynchronize(h->stream));
-    RFLU_HIP(hipMemcpy(out512, (char*)h->pscratch + panel_trace_offset_bytes(), 8 * NB * sizeof(long long), hipMemcpyDeviceToHost));
+    RFLU_HIP(hipMemcpy(out512, (char*)h->pscratch + panel_trace_offset_bytes(), (8 * NB + 16) * sizeof(long long), hipMemcpyDeviceToHost));
     return RFLU_OK;
 }
 

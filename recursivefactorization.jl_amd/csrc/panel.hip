@@ -270,6 +270,53 @@ __device__ __forceinline__ void store_rows(T* R, int64_t ld, int c0, int w, cons
     }
 }
 
+// ---- direct row <-> register transfer: every thread moves its own row with 16-byte accesses, all in flight at once
+// (one memory latency for the whole slab instead of 8 staged LDS round trips); each lane touches whole 128-byte lines.
+template <typename T>
+__device__ __forceinline__ void load_row_direct(const T* __restrict__ R, int64_t ld, int row, bool valid, int c0, int w,
+                                                T (&a)[NB])
+{
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    const T* p = R + (int64_t)row * ld + c0;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+    if (valid && vec_ok && w == NB) {
+#pragma unroll
+        for (int j = 0; j < NB; j += VW) {
+            const vec_t x = *reinterpret_cast<const vec_t*>(p + j);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) a[j + e] = x[e];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[j] = (valid && j < w) ? p[j] : T(0);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_row_direct(T* __restrict__ R, int64_t ld, unsigned pos, int c0, int w,
+                                                 const T (&a)[NB])
+{
+    if (pos == POS_NONE) return;
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    T* p = R + (int64_t)pos * ld + c0;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+    if (vec_ok && w == NB) {
+#pragma unroll
+        for (int j = 0; j < NB; j += VW) {
+            vec_t x;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) x[e] = a[j + e];
+            *reinterpret_cast<vec_t*>(p + j) = x;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (j < w) p[j] = a[j];
+    }
+}
+
 // =====================================================================================================================
 // Pivoted leaf panel
 // =====================================================================================================================
@@ -350,8 +397,13 @@ template <typename T>
 __device__ __forceinline__ void wave_argmax(T& v, unsigned& p)
 {
     const T m = wave_max<T>(v);
-    const unsigned cand = (v == m) ? p : POS_NONE;
-    p = wave_min_u32(cand);
+    const bool hit = (v == m) && (p != POS_NONE);
+    const u64 mask = __ballot(hit);
+    if (__popcll(mask) == 1) {  // the usual case: one lane holds the maximum -> its position by one readlane
+        p = (unsigned)__builtin_amdgcn_readlane((int)p, __ffsll((long long)mask) - 1);
+    } else {                     // exact ties (or no candidate at all): lowest position among the lanes holding the max
+        p = wave_min_u32(hit ? p : POS_NONE);
+    }
     v = m;
 }
 
@@ -578,18 +630,23 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_kernel(PanelArgs<T>
     const int w = p.w;
     const int row_base = p.r0 + g * PANEL_THREADS;
 
+    RFLU_STAMP(p.scratch, NB, 0, g, tid);
     T a[1][NB];
     const int row = row_base + tid;
     bool act = row < p.m;                          // still a pivot candidate (not yet chosen, inside the matrix)
     unsigned pos = act ? (unsigned)row : POS_NONE; // current row position of this thread's row
     if (tid == 0) sh->dead = 0;
-    load_rows<T, 1>(p.R, p.ld, row_base, p.m, p.c0, w, a, sh->tile, wave, lane);
+    load_row_direct<T>(p.R, p.ld, row, act, p.c0, w, a[0]);
+    __syncthreads();
+    RFLU_STAMP(p.scratch, NB, 1, g, tid);
 
     bool dead = false;  // set (workgroup-uniformly) after a timeout: skip the remaining steps quickly
     PivotSteps<T, 0, NB>::run(p, sh, a[0], pos, act, dead, g, tid);
 
-    unsigned posv[1] = {pos};
-    store_rows<T, 1>(p.R, p.ld, p.c0, w, a, posv, sh->tile, sh->spos, wave, lane);
+    RFLU_STAMP(p.scratch, NB, 2, g, tid);
+    store_row_direct<T>(p.R, p.ld, pos, p.c0, w, a[0]);
+    __syncthreads();
+    RFLU_STAMP(p.scratch, NB, 3, g, tid);
 
     if (g == 0 && wave == PANEL_WAVES - 1) {
         __threadfence_block();
@@ -737,7 +794,7 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
 template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 template int launch_panel<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 
-size_t panel_scratch_bytes() { return (PS_TOTAL_WORDS + 8 * NB) * sizeof(u64); }  // + room for RFLU_PANEL_TRACE stamps
+size_t panel_scratch_bytes() { return (PS_TOTAL_WORDS + 8 * NB + 16) * sizeof(u64); }  // + room for RFLU_PANEL_TRACE stamps
 size_t panel_trace_offset_bytes() { return PS_TOTAL_WORDS * sizeof(u64); }
 
 }  // namespace rflu

@@ -15,13 +15,15 @@ for m in [int(x) for x in (sys.argv[1:] or ["256", "2048", "16384"])]:
     for _ in range(3):
         A = A0.clone()
         h.call("rflu_panel_rm_f64_dev", m, 0, 0, 64, P(A), 64, P(ip), 1, ctypes.byref(info))
-    buf = np.zeros(512, dtype=np.int64)
+    buf = np.zeros(528, dtype=np.int64)
     lib.rflu_debug_panel_trace(h.ptr, buf.ctypes.data)
-    st = buf.reshape(64, 8)[:, :7].astype(np.float64)
+    ex = buf[512:516].astype(np.float64)
+    st = buf[:512].reshape(64, 8)[:, :7].astype(np.float64)
     d = np.diff(st, axis=1)
     tot = st[:, 6] - st[:, 0]
     gap = st[1:, 0] - st[:-1, 6]
     print(f"m={m}: avg cycles per step (thread 0 of WG 0):")
     for i, n in enumerate(names[:6]):
         print(f"   {n:10s} {d[:, i].mean():8.0f}   (k=0: {d[0, i]:6.0f}, k=32: {d[32, i]:6.0f}, k=63: {d[63, i]:6.0f})")
+    print(f"   kernel entry->rows loaded {ex[1]-ex[0]:.0f} cyc; loaded->step0 {st[0,0]-ex[1]:.0f}; last step->store start {ex[2]-st[63,6]:.0f}; store {ex[3]-ex[2]:.0f}; entry->end {(ex[3]-ex[0])/2.4e3:.1f} us")
     print(f"   {'total':10s} {tot.mean():8.0f}  inter-step gap {gap.mean():6.0f};  whole kernel steps {(st[63,6]-st[0,0]):.0f} cycles = {(st[63,6]-st[0,0])/2.4e3:.1f} us")

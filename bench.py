@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- LU GFLOP/s (2n^3/3) of the MI355X-native recursive LU, the metric of BASELINE.json.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n SIZE] [--dtype f64|f32] [--nopivot] [--blocksize B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size SIZE] [--dtype f64|f32] [--nopivot] [--blocksize B]
 
 A "step" is one factorization  lu!(A, ipiv)  of a dense uniform [0,1) n x n matrix that is already resident in HBM in
 the reference's column-major layout; the result (packed L\\U, ipiv) is left in HBM.  The input is regenerated on the
@@ -9,7 +9,7 @@ device before every step (untimed); each step is bracketed by barrier + device s
 K step times are summed (max over ranks), so `value` = K * (2n^3/3) / sum(t_step).
 
 Workloads (BASELINE.json configs): 1 GPU -> n = 16384 (config 2, the one the 70 %-of-peak target is quoted on);
-2 and 4 GPUs -> n = 32768 (config 3); 8 GPUs -> n = 65536 (config 4); --n overrides.
+2 and 4 GPUs -> n = 32768 (config 3); 8 GPUs -> n = 65536 (config 4); --size overrides.
 
 Extra objects on the JSON line:
   roofline     dominant kernel = the MFMA GEMM update (schur_complement!): algorithmic 2*M*N*K flops of every launch of
@@ -39,7 +39,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--size", "--n", dest="n", type=int, default=0,
+                    help="matrix size (use --size under torchrun: its own parser treats --n as ambiguous)")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--nopivot", action="store_true")
     ap.add_argument("--blocksize", type=int, default=0)
@@ -111,8 +112,14 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("RFLU_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with a single rank (testing)
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.n or DEFAULT_N.get(args.gpus, 16384 * max(1, args.gpus // 2))
@@ -125,11 +132,12 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    if world == 1:
+    single = world == 1 and not force_dist
+    if single:
         A = torch.empty((n, n), dtype=tdt, device=dev)  # memory = column-major n x n (lda = n)
         ipiv = torch.empty(n, dtype=torch.int64, device=dev)
         info = ctypes.c_int64(0)
@@ -143,7 +151,8 @@ def main():
     else:
         from recursivefactorization.jl_amd import distributed as D
 
-        job = D.BlockColumnLU(D.HipOps(h, sfx), n, tdt, rank, world, dev, block=args.block, pivot=bool(pivot), seed=SEED)
+        job = D.BlockColumnLU(D.HipOps(h, sfx), n, tdt, rank, world, dev, block=args.block, pivot=bool(pivot), seed=SEED,
+                              always_broadcast=force_dist)
         regenerate = job.regenerate
         step = job.factor
 
@@ -160,7 +169,7 @@ def main():
         barrier()
         times.append(time.perf_counter() - t0)
     total = torch.tensor([sum(times)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(total, op=dist.ReduceOp.MAX)
     total_s = float(total.item())
     ms_per_step = 1e3 * total_s / max(args.steps, 1)
@@ -169,7 +178,7 @@ def main():
     # ---- roofline of the dominant kernel: one extra profiled factorization (HIP events on the launch stream) ----
     roof = None
     kern = {}
-    if world == 1:
+    if single:
         regenerate()
         barrier()
         h.profile_enable(True)
@@ -187,7 +196,7 @@ def main():
 
     # ---- checks on the last factorization: residual on device (torch as an independent checker) ----
     check = {}
-    if not args.no_check and world == 1 and n <= 32768:
+    if not args.no_check and single and n <= 32768:
         regenerate()
         barrier()
         A0 = A.clone()  # column-major memory; A.T is the logical matrix in torch's row-major view
@@ -216,12 +225,12 @@ def main():
         check["info"] = int(info.value)
         del L, U, R, PA
 
-    if not args.no_check and world > 1:
+    if not args.no_check and not single:
         check["residual_matvec"] = job.matvec_residual()
         check["info"] = int(job.info)
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and single:
         cpu, cpu_ipiv = cpu_baseline(args.cpu_n)
         if pivot and sfx == "f64":
             # ipiv parity on the CPU sample size: same generator, same seed -> must be bit-exact
@@ -252,7 +261,7 @@ def main():
             "kernel_ms": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in kern.items()},
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -76,12 +76,14 @@ def block_layout(n: int, block: int, world: int):
 class BlockColumnLU:
     """Factor an n x n matrix distributed by block columns.  ``factor()`` is one step of bench.py's --gpus N path."""
 
-    def __init__(self, ops, n, dtype, rank, world, device, *, block=512, pivot=True, seed=12, diag_add=0.0, group=None):
+    def __init__(self, ops, n, dtype, rank, world, device, *, block=512, pivot=True, seed=12, diag_add=0.0, group=None,
+                 always_broadcast=False):
         if block % NB:
             raise ValueError("block must be a multiple of 64")
         self.ops, self.n, self.rank, self.world, self.device = ops, n, rank, world, device
         self.block, self.pivot, self.seed, self.diag_add, self.group = block, pivot, seed, diag_add, group
         self.dtype = dtype
+        self.collective = world > 1 or always_broadcast  # always_broadcast: exercise the RCCL calls with one rank
         self.layout, local_cols = block_layout(n, block, world)
         self.n_loc = local_cols[rank]
         self.ld = max(16, (self.n_loc + 15) // 16 * 16)
@@ -121,13 +123,13 @@ class BlockColumnLU:
                 self.meta[:w].copy_(self.ipiv[j0:j0 + w])
                 self.meta[w] = info
             # ---- the one exchange step of the path: panel + pivots, owner -> everybody ----
-            if self.world > 1:
+            if self.collective:
                 src = owner if self.group is None else dist.get_global_rank(self.group, owner)
                 dist.broadcast(panel, src=src, group=self.group)
                 dist.broadcast(self.meta[: w + 1], src=src, group=self.group)
             if self.rank != owner:
                 self.ipiv[j0:j0 + w].copy_(self.meta[:w])
-            info = int(self.meta[w].item()) if self.world > 1 or self.rank == owner else 0
+            info = int(self.meta[w].item())
             if info != 0 and self.info == 0:
                 self.info = info
             # ---- local columns: left of the panel (finished L columns) and right of it (trailing) ----
@@ -154,7 +156,7 @@ class BlockColumnLU:
             blk = torch.zeros((self.n, w), dtype=self.dtype, device=self.device)
             if owner == self.rank:
                 blk.copy_(self.R[:, lc:lc + w])
-            if self.world > 1:
+            if self.collective:
                 src = owner if self.group is None else dist.get_global_rank(self.group, owner)
                 dist.broadcast(blk, src=src, group=self.group)
             full[:, j0:j0 + w] = blk
@@ -186,11 +188,11 @@ class BlockColumnLU:
             xl = x[cols]
             ax = A.to(torch.float64) @ xl.to(torch.float64)
             ux = Uloc.to(torch.float64) @ xl.to(torch.float64)
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(ax, group=self.group)
                 dist.all_reduce(ux, group=self.group)
             lz = Lloc.to(torch.float64) @ ux[cols] + torch.zeros(n, dtype=torch.float64, device=dev)
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(lz, group=self.group)
             lz = lz + ux  # unit diagonal of L
             r = torch.linalg.norm(ax[perm] - lz) / torch.linalg.norm(ax)

@@ -106,6 +106,7 @@ struct Fact {
     int64_t* ipiv;
     int pivot;
     int64_t sw_lo = 0, sw_hi = -1;  // column range that receives a leaf's interchanges right away ([0, n) by default)
+    hipEvent_t gate = nullptr;      // if set: wait for it after the next leaf's panel kernel, before its interchanges
 
     T* linv_at(int64_t row) const { return static_cast<T*>(h->linv) + (row / NB) * NB * NB; }
 
@@ -113,6 +114,10 @@ struct Fact {
     int leaf(int64_t c0, int64_t w)
     {
         RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, ipiv, pivot));
+        if (gate) {  // lookahead: the other columns of this block column are still being updated on the second stream
+            RFLU_HIP(hipStreamWaitEvent(h->stream, gate, 0));
+            gate = nullptr;
+        }
         const int64_t hi = sw_hi < 0 ? n : sw_hi;
         // one launch: the leaf's interchanges on the other columns + the inverse of its diagonal block (fused TRSMs)
         if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, sw_lo, c0 - sw_lo, c0 + w, hi - (c0 + w), c0 / NB, c0 / NB + 1, w,
@@ -180,8 +185,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
 {
     Handle* h = f.h;
     {
-        const int64_t wgs = (f.m + PANEL_THREADS - 1) / PANEL_THREADS;  // workgroups of the tallest panel
-        int reserve = wgs <= 32 ? 32 : (wgs <= 64 ? 64 : 128);
+        int reserve = 32;
         if (const char* e = getenv("RFLU_RESERVE_CUS")) {  // tuning knob: CUs kept away from the update stream
             const int v = atoi(e);
             if (v >= 32 && v <= 224 && v % 32 == 0) reserve = v;
@@ -219,7 +223,14 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
         f.sw_lo = j0;
         f.sw_hi = je;
         RFLU_TRY(f.rec(j0, je));
-        RFLU_TRY(get_event(h, 1 + 2 * b, &ev));
+        // A panel taller than 32 workgroups would need more than the 32 CUs kept free for it, and at that height the
+        // trailing update dwarfs the panel anyway (GEMM-bound): run such block columns on one stream, whole GPU each.
+        if ((m - j0 + PANEL_THREADS - 1) / PANEL_THREADS > h->ustream_reserve) {
+            if (f.pivot && j0 > 0) RFLU_TRY(launch_laswp<T>(h, R, ld, 0, j0, j0 / NB, (je + NB - 1) / NB));
+            RFLU_TRY(update(P, j0, jb, je, n));
+            continue;
+        }
+        RFLU_TRY(get_event(h, 1 + 3 * b, &ev));
         RFLU_HIP(hipEventRecord(ev, P));
         RFLU_HIP(hipStreamWaitEvent(U, ev, 0));
         // ---- U: interchanges on the finished columns to the left ----
@@ -233,20 +244,23 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
         if (je >= n) break;
         const int64_t n1e = std::min(je + W, n);                                            // end of block column b+1
         const int64_t n2e = std::min(n1e + W, n);                                           // end of block column b+2
-        // ---- P: next block column (needs rest_{b-1}.part1, which updated exactly these columns) ----
+        // ---- P: next block column (needs rest_{b-1}.part1, which updated exactly these columns).  Handing all but its
+        // first leaf to U (and gating P's second leaf on it) was measured slower: U's in-order queue is still busy with
+        // rest_{b-1} in the early, update-bound block columns.
         if (b > 0) {
-            RFLU_TRY(get_event(h, 2 + 2 * (b - 1), &ev));
+            RFLU_TRY(get_event(h, 3 + 3 * (b - 1), &ev));
             RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
         }
         RFLU_TRY(update(P, j0, jb, je, n1e));
         // ---- U: block column b+2 first (the next `next`), then everything further right ----
         RFLU_TRY(update(U, j0, jb, n1e, n2e));
-        RFLU_TRY(get_event(h, 2 + 2 * b, &ev));
+        RFLU_TRY(get_event(h, 3 + 3 * b, &ev));
         RFLU_HIP(hipEventRecord(ev, U));
         RFLU_TRY(update(U, j0, jb, n2e, n));
     }
     f.sw_lo = 0;
     f.sw_hi = -1;
+    f.gate = nullptr;
     // join: P continues only after U has drained
     RFLU_TRY(get_event(h, 0, &ev));
     RFLU_HIP(hipEventRecord(ev, U));
@@ -277,7 +291,8 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
 
     Fact<T> f{h, R, ld, m, n, ipiv, pivot};
     bool fat_tail_done = false;
-    if (blocksize == 0) blocksize = (mn >= 4096) ? 1024 : -1;
+    if (blocksize == 0)  // measured on MI355X (bench.py --blocksize sweep): the knee moves right with the matrix size
+        blocksize = mn < 1024 ? -1 : (mn <= 8192 ? 256 : (mn <= 16384 ? 512 : (mn <= 32768 ? 1024 : 2048)));
     if (blocksize < 0 || blocksize >= mn) {
         h->last_path = RFLU_PATH_HIP_RECURSIVE;
         RFLU_TRY(f.rec(0, mn));
@@ -410,7 +425,14 @@ int rflu_create(rflu_handle_t* handle, int device)
     h->num_cus = prop.multiProcessorCount;
     // a BLOCKING stream: it orders itself against the legacy default stream, so buffers produced by a framework on
     // stream 0 (PyTorch's default) need no extra synchronisation before/after a call
-    RFLU_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault));
+    {
+        // highest priority: in the lookahead driver this stream carries the critical path (panels + next block column)
+        // and competes for CUs with the bulk trailing update on the second stream
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (getenv("RFLU_NO_PRIORITY")) hi = 0;
+        RFLU_HIP(hipStreamCreateWithPriority(&h->own_stream, hipStreamDefault, hi));
+    }
     h->stream = h->own_stream;
     RFLU_HIP(hipMalloc((void**)&h->info_dev, 2 * sizeof(int64_t)));
     RFLU_HIP(hipHostMalloc((void**)&h->info_pinned, 2 * sizeof(int64_t)));

@@ -189,10 +189,21 @@ def main():
         g = kern["gemm"]
         if g["launches"] > 0 and g["ms"] > 0:
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
+            traffic = None
+            try:  # HBM bytes per launch from the committed PMC passes of this exact workload (profiles/), if present
+                with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as f:
+                    tj = json.load(f)
+                if tj.get("n") == n and tj.get("dtype") == sfx:
+                    traffic = tj["hbm_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
             roof = {"bound": "mfma", "kernel": "gemm_sub_kernel (schur_complement!, C -= A*B)", "achieved": round(ach, 3),
-                    "peak": PEAK_TFLOPS[sfx], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[sfx], 4), "traffic": None,
+                    "peak": PEAK_TFLOPS[sfx], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[sfx], 4), "traffic": traffic,
                     "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                    "flops_per_factorization": g["work"]}
+                    "flops_per_launch": g["work"] / g["launches"],
+                    "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
+                    "note": "all GEMM launches of one profiled factorization (single-stream blocked schedule, HIP events "
+                            "on the launch stream); traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 per launch from profiles/*pmc*"}
 
     # ---- checks on the last factorization: residual on device (torch as an independent checker) ----
     check = {}

@@ -138,6 +138,8 @@ int rflu_fill_uniform_f32_dev(rflu_handle_t handle, float* A_dev, int64_t m, int
  * algorithmic work (flops for GEMM/TRSM/PANEL, bytes for LASWP/TRANSPOSE) of class k since enabling. */
 int rflu_profile_enable(rflu_handle_t handle, int enable);
 int rflu_profile_get(rflu_handle_t handle, int kclass, double* ms, int64_t* launches, double* work);
+/* algorithmic (minimum) HBM bytes of the launches of class k since enabling (GEMM: A and B once, C in and out) */
+int rflu_profile_get_bytes(rflu_handle_t handle, int kclass, double* bytes);
 
 #ifdef __cplusplus
 }

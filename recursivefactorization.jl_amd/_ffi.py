@@ -45,6 +45,7 @@ _PLAIN = {
     "rflu_last_path": (c_int, [c_p]),
     "rflu_profile_enable": (c_int, [c_p, c_int]),
     "rflu_profile_get": (c_int, [c_p, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
+    "rflu_profile_get_bytes": (c_int, [c_p, c_int, ctypes.POINTER(c_dbl)]),
 }
 
 EXPORTS = dict(_PLAIN)
@@ -130,7 +131,9 @@ class Handle:
         for k, name in enumerate(KCLASS_NAMES):
             ms, n, work = c_dbl(), c_i64(), c_dbl()
             check(self.lib.rflu_profile_get(self.ptr, k, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(work)))
-            out[name] = {"ms": ms.value, "launches": n.value, "work": work.value}
+            by = c_dbl()
+            check(self.lib.rflu_profile_get_bytes(self.ptr, k, ctypes.byref(by)))
+            out[name] = {"ms": ms.value, "launches": n.value, "work": work.value, "bytes": by.value}
         return out
 
 

@@ -613,4 +613,12 @@ int rflu_profile_get(rflu_handle_t handle, int kclass, double* ms, int64_t* laun
     return RFLU_OK;
 }
 
+int rflu_profile_get_bytes(rflu_handle_t handle, int kclass, double* bytes)
+{
+    CHECK_HANDLE(handle);
+    if (kclass < 0 || kclass >= RFLU_K_COUNT || bytes == nullptr) { set_error("bad kernel class %d", kclass); return RFLU_ERR_ARG; }
+    *bytes = H(handle)->slots[kclass].bytes;
+    return RFLU_OK;
+}
+
 }  // extern "C"

@@ -41,6 +41,7 @@ struct ProfSlot {
     double ms = 0.0;
     int64_t launches = 0;
     double work = 0.0;
+    double bytes = 0.0;  // algorithmic (minimum) HBM bytes of the launches
 };
 
 struct Handle {
@@ -89,8 +90,9 @@ struct ProfScope {
     Handle* h;
     int k;
     double work;
+    double bytes;
     bool on;
-    ProfScope(Handle* h_, int k_, double work_) : h(h_), k(k_), work(work_), on(h_->prof) {
+    ProfScope(Handle* h_, int k_, double work_, double bytes_ = 0.0) : h(h_), k(k_), work(work_), bytes(bytes_), on(h_->prof) {
         if (on) (void)hipEventRecord(h->ev0, h->stream);
     }
     ~ProfScope() {
@@ -102,6 +104,7 @@ struct ProfScope {
             h->slots[k].ms += ms;
             h->slots[k].launches += 1;
             h->slots[k].work += work;
+            h->slots[k].bytes += bytes;
         }
     }
 };

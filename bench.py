@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--blocksize", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=4096)
+    ap.add_argument("--cpu-n", type=int, default=6144, help="size of the bounded CPU-baseline sample (~10-30 s of CPU work)")
     ap.add_argument("--block", type=int, default=512, help="block-column width of the multi-GPU layout")
     return ap.parse_args()
 

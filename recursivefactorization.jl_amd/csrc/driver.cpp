@@ -106,27 +106,25 @@ struct Fact {
     int64_t* ipiv;
     int pivot;
     int64_t sw_lo = 0, sw_hi = -1;  // column range that receives a leaf's interchanges right away ([0, n) by default)
+    int64_t roff = 0;               // row of the diagonal minus its column (non-zero for a block column of a slab)
     hipEvent_t gate = nullptr;      // if set: wait for it after the next leaf's panel kernel, before its interchanges
 
     T* linv_at(int64_t row) const { return static_cast<T*>(h->linv) + (row / NB) * NB * NB; }
 
-    // leaf: rows [c0, m), columns [c0, c0+w): cooperative panel + the interchanges on every other column
+    // leaf: rows [c0+roff, m), columns [c0, c0+w): cooperative panel + the interchanges on every other column
     int leaf(int64_t c0, int64_t w)
     {
-        RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, ipiv, pivot));
-        if (gate) {  // lookahead: the other columns of this block column are still being updated on the second stream
-            RFLU_HIP(hipStreamWaitEvent(h->stream, gate, 0));
-            gate = nullptr;
-        }
+        const int64_t r0 = c0 + roff;
+        RFLU_TRY(launch_panel<T>(h, R, ld, m, r0, c0, w, ipiv, pivot));
         const int64_t hi = sw_hi < 0 ? n : sw_hi;
         // one launch: the leaf's interchanges on the other columns + the inverse of its diagonal block (fused TRSMs)
-        if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, sw_lo, c0 - sw_lo, c0 + w, hi - (c0 + w), c0 / NB, c0 / NB + 1, w,
-                                             R + c0 * ld + c0, linv_at(c0)));
-        else RFLU_TRY(launch_diag_inv<T>(h, w, R + c0 * ld + c0, ld, linv_at(c0)));
+        if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, sw_lo, c0 - sw_lo, c0 + w, hi - (c0 + w), r0 / NB, r0 / NB + 1, w,
+                                             R + r0 * ld + c0, linv_at(r0)));
+        else RFLU_TRY(launch_diag_inv<T>(h, w, R + r0 * ld + c0, ld, linv_at(r0)));
         return RFLU_OK;
     }
 
-    // reckernel! (src/lu.jl:189-263) on columns [c0, c1), rows [c0, m)
+    // reckernel! (src/lu.jl:189-263) on columns [c0, c1), rows [c0+roff, m)
     int rec(int64_t c0, int64_t c1)
     {
         const int64_t w = c1 - c0;
@@ -136,12 +134,12 @@ struct Fact {
         const int64_t n1 = ((leaves + 1) / 2) * NB;
         const int64_t cm = c0 + n1;
         RFLU_TRY(rec(c0, cm));
-        T* A11 = R + c0 * ld + c0;
-        T* A12 = R + c0 * ld + cm;
-        T* A21 = R + cm * ld + c0;
-        T* A22 = R + cm * ld + cm;
-        RFLU_TRY(trsm_rec<T>(h, n1, c1 - cm, A11, ld, A12, ld, linv_at(c0)));           // src/lu.jl:235
-        RFLU_TRY(launch_gemm<T>(h, m - cm, c1 - cm, n1, A21, ld, A12, ld, A22, ld));    // src/lu.jl:240
+        T* A11 = R + (c0 + roff) * ld + c0;
+        T* A12 = R + (c0 + roff) * ld + cm;
+        T* A21 = R + (cm + roff) * ld + c0;
+        T* A22 = R + (cm + roff) * ld + cm;
+        RFLU_TRY(trsm_rec<T>(h, n1, c1 - cm, A11, ld, A12, ld, linv_at(c0 + roff)));              // src/lu.jl:235
+        RFLU_TRY(launch_gemm<T>(h, m - (cm + roff), c1 - cm, n1, A21, ld, A12, ld, A22, ld));     // src/lu.jl:240
         return rec(cm, c1);
     }
 };
@@ -516,23 +514,12 @@ int rflu_last_path(rflu_handle_t handle) { return handle ? H(handle)->last_path 
         RFLU_TRY(ensure_bookkeeping(h, m));                                                                           \
         RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), h->stream));                                     \
         if (!pivot && ipiv) RFLU_TRY(launch_iota_ipiv(h, ipiv, r0, w));                                               \
-        /* wide panels are factored by the same recursion, restricted to columns [c0, c0+w) with diagonal at r0 */   \
-        for (int64_t j = 0; j < w; j += NB) {                                                                         \
-            const int64_t jb = std::min<int64_t>(NB, w - j);                                                          \
-            if (j > 0) {                                                                                              \
-                RFLU_TRY(trsm_rec<T>(h, j, jb, R + r0 * ld + c0, ld, R + r0 * ld + c0 + j, ld,                        \
-                                     static_cast<T*>(h->linv) + (r0 / NB) * NB * NB));                                \
-                RFLU_TRY(launch_gemm<T>(h, m - r0 - j, jb, j, R + (r0 + j) * ld + c0, ld, R + r0 * ld + c0 + j, ld,   \
-                                        R + (r0 + j) * ld + c0 + j, ld));                                             \
-            }                                                                                                         \
-            RFLU_TRY(launch_panel<T>(h, R, ld, m, r0 + j, c0 + j, jb, ipiv, pivot));                                  \
-            if (pivot)                                                                                                \
-                RFLU_TRY(launch_laswp2<T>(h, R, ld, c0, j, c0 + j + jb, w - j - jb, (r0 + j) / NB, (r0 + j) / NB + 1,   \
-                                          jb, R + (r0 + j) * ld + c0 + j,                                             \
-                                          static_cast<T*>(h->linv) + ((r0 + j) / NB) * NB * NB));                     \
-            else                                                                                                      \
-                RFLU_TRY(launch_diag_inv<T>(h, jb, R + (r0 + j) * ld + c0 + j, ld,                                    \
-                                            static_cast<T*>(h->linv) + ((r0 + j) / NB) * NB * NB));                   \
+        /* wide panels are factored by the same Toledo recursion as the single-GPU path, restricted to the columns   \
+           [c0, c0+w) of the slab, diagonal at (r0, c0), interchanges confined to those columns */                   \
+        {                                                                                                             \
+            Fact<T> f{h, R, ld, m, c0 + w, ipiv, pivot};                                                              \
+            f.sw_lo = c0; f.sw_hi = c0 + w; f.roff = r0 - c0;                                                         \
+            RFLU_TRY(f.rec(c0, c0 + w));                                                                              \
         }                                                                                                             \
         RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); \
         RFLU_HIP(hipStreamSynchronize(h->stream));                                                                    \

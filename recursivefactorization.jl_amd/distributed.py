@@ -94,6 +94,7 @@ class BlockColumnLU:
         # bytes would lose int64 pivots for Float32, so pivots travel in a second int64 message appended to the first
         self.pbuf = torch.zeros(n * wmax, dtype=dtype, device=device)
         self.meta = torch.zeros(wmax + 1, dtype=torch.int64, device=device)   # ipiv segment + info
+        self.info_dev = torch.zeros((), dtype=torch.int64, device=device)
         self.info = 0
 
     # ---- input -------------------------------------------------------------------------------------------------------
@@ -112,6 +113,7 @@ class BlockColumnLU:
     def factor(self):
         n, ld, ops = self.n, self.ld, self.ops
         self.info = 0
+        self.info_dev.zero_()
         if not self.pivot:
             self.ipiv.copy_(torch.arange(1, n + 1, dtype=torch.int64, device=self.device))
         for (j0, w, owner, lc) in self.layout:
@@ -129,9 +131,8 @@ class BlockColumnLU:
                 dist.broadcast(self.meta[: w + 1], src=src, group=self.group)
             if self.rank != owner:
                 self.ipiv[j0:j0 + w].copy_(self.meta[:w])
-            info = int(self.meta[w].item())
-            if info != 0 and self.info == 0:
-                self.info = info
+            # first non-zero info wins; kept on the device so that no block column forces a host synchronisation
+            self.info_dev.copy_(torch.where(self.info_dev == 0, self.meta[w], self.info_dev))
             # ---- local columns: left of the panel (finished L columns) and right of it (trailing) ----
             if self.rank == owner:
                 left_end, right_start = lc, lc + w
@@ -146,6 +147,7 @@ class BlockColumnLU:
                 ops.trsm(w, nt, self.pbuf, 0, w, self.R, j0 * ld + right_start, ld)
                 ops.gemm(rows - w, nt, w, self.pbuf, w * w, w, self.R, j0 * ld + right_start, ld,
                          self.R, (j0 + w) * ld + right_start, ld)
+        self.info = int(self.info_dev.item())
         return self.info
 
     # ---- results -------------------------------------------------------------------------------------------------------

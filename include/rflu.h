@@ -63,6 +63,10 @@ int rflu_version(void);
 int rflu_set_stream(rflu_handle_t handle, void* hip_stream);
 int rflu_synchronize(rflu_handle_t handle);
 int rflu_last_path(rflu_handle_t handle);
+/* The handle's second stream (hipStream_t as void*): restricted by a CU mask to 224 of the 256 CUs so that cooperative
+ * panel kernels issued on another stream always find 32 free CUs.  Used by the lookahead drivers (single- and
+ * multi-GPU) for the bulk trailing updates. */
+int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out);
 
 /* ---- the boundary: lu!(A, ipiv, pivot; blocksize) on HOST buffers (caller-owned, column-major) ----
  * Replaces src/lu.jl:114-126 (recursive path + unblocked fallback) for Float64 / Float32.

@@ -43,6 +43,7 @@ _PLAIN = {
     "rflu_set_stream": (c_int, [c_p, c_p]),
     "rflu_synchronize": (c_int, [c_p]),
     "rflu_last_path": (c_int, [c_p]),
+    "rflu_update_stream": (c_int, [c_p, ctypes.POINTER(c_p)]),
     "rflu_profile_enable": (c_int, [c_p, c_int]),
     "rflu_profile_get": (c_int, [c_p, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
     "rflu_profile_get_bytes": (c_int, [c_p, c_int, ctypes.POINTER(c_dbl)]),
@@ -122,6 +123,12 @@ class Handle:
 
     def synchronize(self):
         check(self.lib.rflu_synchronize(self.ptr))
+
+    def update_stream(self) -> int:
+        """hipStream_t (as int) of the CU-masked update stream."""
+        out = c_p()
+        check(self.lib.rflu_update_stream(self.ptr, ctypes.byref(out)))
+        return int(out.value)
 
     def profile_enable(self, on: bool):
         check(self.lib.rflu_profile_enable(self.ptr, int(bool(on))))

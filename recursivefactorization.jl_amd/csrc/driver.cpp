@@ -157,7 +157,7 @@ static int get_event(Handle* h, size_t idx, hipEvent_t* ev)
 
 // The update stream leaves `reserve` CUs (a multiple of 32) to the critical-path stream so that the cooperative panel
 // kernel (one 512-thread workgroup per CU) finds all its workgroups a home at once.
-static int ensure_ustream(Handle* h, int reserve)
+int ensure_ustream(Handle* h, int reserve)
 {
     if (h->ustream && h->ustream_reserve == reserve) return RFLU_OK;
     if (h->ustream) { RFLU_HIP(hipStreamSynchronize(h->ustream)); RFLU_HIP(hipStreamDestroy(h->ustream)); h->ustream = nullptr; }
@@ -384,6 +384,7 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
 using namespace rflu;
 
 static Handle* H(rflu_handle_t h) { return reinterpret_cast<Handle*>(h); }
+namespace rflu { int ensure_ustream(Handle* h, int reserve); }
 
 #define CHECK_HANDLE(h)                        \
     do {                                       \
@@ -484,6 +485,15 @@ int rflu_synchronize(rflu_handle_t handle)
 }
 
 int rflu_last_path(rflu_handle_t handle) { return handle ? H(handle)->last_path : RFLU_PATH_NONE; }
+
+int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out)
+{
+    CHECK_HANDLE(handle);
+    if (hip_stream_out == nullptr) { set_error("null output pointer"); return RFLU_ERR_ARG; }
+    RFLU_TRY(ensure_ustream(H(handle), 32));
+    *hip_stream_out = reinterpret_cast<void*>(H(handle)->ustream);
+    return RFLU_OK;
+}
 
 #define DEFINE_TYPED(SFX, T)                                                                                          \
     int rflu_getrf_##SFX(rflu_handle_t handle, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv, int pivot,     \

@@ -17,6 +17,7 @@ is exercised on CPU under gloo in tests/test_distributed.py with a NumPy stand-i
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -35,6 +36,17 @@ class HipOps:
 
     def _p(self, t, off=0):
         return ctypes.c_void_p(t.data_ptr() + off * self.es)
+
+    # ---- streams of the lookahead schedule (None on the CPU stand-in) ----
+    def make_streams(self, device):
+        """(update stream U: CU-masked, from librflu;  panel stream P: an ordinary side stream)."""
+        U = torch.cuda.ExternalStream(self.h.update_stream(), device=device)
+        P = torch.cuda.Stream(device=device)
+        return U, P
+
+    def use(self, stream):
+        """Route the following kernel launches of the library to ``stream``."""
+        self.h.set_stream(stream.cuda_stream if stream is not None else None)
 
     def panel(self, R, ld, m, r0, c0, w, ipiv, pivot) -> int:
         info = ctypes.c_int64(0)
@@ -92,8 +104,8 @@ class BlockColumnLU:
         wmax = min(block, n)
         # one message per block column: [panel rows j0..n) x w | ipiv segment | info], all carried as the matrix dtype's
         # bytes would lose int64 pivots for Float32, so pivots travel in a second int64 message appended to the first
-        self.pbuf = torch.zeros(n * wmax, dtype=dtype, device=device)
-        self.meta = torch.zeros(wmax + 1, dtype=torch.int64, device=device)   # ipiv segment + info
+        self.pbuf = [torch.zeros(n * wmax, dtype=dtype, device=device) for _ in range(2)]       # double-buffered by parity
+        self.meta = [torch.zeros(wmax + 1, dtype=torch.int64, device=device) for _ in range(2)]  # ipiv segment + info
         self.info_dev = torch.zeros((), dtype=torch.int64, device=device)
         self.info = 0
 
@@ -110,43 +122,158 @@ class BlockColumnLU:
                 self.R[:, lc:lc + w] = torch.as_tensor(np.ascontiguousarray(A[:, j0:j0 + w]), dtype=self.dtype).to(self.device)
 
     # ---- the factorization ---------------------------------------------------------------------------------------------
+    def _local_ranges(self, j0, w, owner, lc):
+        """(end of the local columns left of block column (j0,w), start of the local columns right of it)."""
+        if self.rank == owner:
+            return lc, lc + w
+        rs = sum(ww for (jj, ww, oo, _) in self.layout if oo == self.rank and jj < j0)
+        return rs, rs
+
+    def _update(self, j0, w, pbuf, c0, ncols):
+        """Apply block column (j0,w), held packed in ``pbuf``, to the local columns [c0, c0+ncols): interchanges,
+        block-row solve against L11, Schur update with L21."""
+        if ncols <= 0:
+            return
+        n, ld, ops = self.n, self.ld, self.ops
+        if self.pivot:
+            ops.laswp(self.R, ld, n, c0, ncols, self.ipiv, j0, j0 + w)
+        ops.trsm(w, ncols, pbuf, 0, w, self.R, j0 * ld + c0, ld)
+        ops.gemm(n - j0 - w, ncols, w, pbuf, w * w, w, self.R, j0 * ld + c0, ld, self.R, (j0 + w) * ld + c0, ld)
+
     def factor(self):
+        if os.environ.get("RFLU_DIST_SYNC") == "1" or len(self.layout) < 2:
+            return self.factor_sync()
+        return self.factor_lookahead()
+
+    def factor_sync(self):
+        """One block column at a time: panel -> broadcast -> update, everything on the current stream."""
         n, ld, ops = self.n, self.ld, self.ops
         self.info = 0
         self.info_dev.zero_()
         if not self.pivot:
             self.ipiv.copy_(torch.arange(1, n + 1, dtype=torch.int64, device=self.device))
+        pbuf_all, meta = self.pbuf[0], self.meta[0]
         for (j0, w, owner, lc) in self.layout:
             rows = n - j0
-            panel = self.pbuf[: rows * w].view(rows, w)
+            panel = pbuf_all[: rows * w].view(rows, w)
             if self.rank == owner:
                 info = ops.panel(self.R, ld, n, j0, lc, w, self.ipiv, self.pivot)
                 panel.copy_(self.R[j0:, lc:lc + w])
-                self.meta[:w].copy_(self.ipiv[j0:j0 + w])
-                self.meta[w] = info
+                meta[:w].copy_(self.ipiv[j0:j0 + w])
+                meta[w] = info
             # ---- the one exchange step of the path: panel + pivots, owner -> everybody ----
             if self.collective:
                 src = owner if self.group is None else dist.get_global_rank(self.group, owner)
                 dist.broadcast(panel, src=src, group=self.group)
-                dist.broadcast(self.meta[: w + 1], src=src, group=self.group)
+                dist.broadcast(meta[: w + 1], src=src, group=self.group)
             if self.rank != owner:
-                self.ipiv[j0:j0 + w].copy_(self.meta[:w])
+                self.ipiv[j0:j0 + w].copy_(meta[:w])
             # first non-zero info wins; kept on the device so that no block column forces a host synchronisation
-            self.info_dev.copy_(torch.where(self.info_dev == 0, self.meta[w], self.info_dev))
-            # ---- local columns: left of the panel (finished L columns) and right of it (trailing) ----
-            if self.rank == owner:
-                left_end, right_start = lc, lc + w
-            else:
-                right_start = sum(ww for (jj, ww, oo, _) in self.layout if oo == self.rank and jj < j0)
-                left_end = right_start
-            nt = self.n_loc - right_start
+            self.info_dev.copy_(torch.where(self.info_dev == 0, meta[w], self.info_dev))
+            left_end, right_start = self._local_ranges(j0, w, owner, lc)
             if self.pivot:
                 ops.laswp(self.R, ld, n, 0, left_end, self.ipiv, j0, j0 + w)
-                ops.laswp(self.R, ld, n, right_start, nt, self.ipiv, j0, j0 + w)
-            if nt > 0:
-                ops.trsm(w, nt, self.pbuf, 0, w, self.R, j0 * ld + right_start, ld)
-                ops.gemm(rows - w, nt, w, self.pbuf, w * w, w, self.R, j0 * ld + right_start, ld,
-                         self.R, (j0 + w) * ld + right_start, ld)
+            self._update(j0, w, pbuf_all, right_start, self.n_loc - right_start)
+        self.info = int(self.info_dev.item())
+        return self.info
+
+    def factor_lookahead(self):
+        """Same operations, one block column of lookahead on two streams:
+             U (CU-masked update stream): per block column b  [wait recv_b]  next-owner slice first, then the bulk update
+             P (panel stream)          : owner of b+1 factors its block column as soon as its slice is updated, packs it,
+                                         and EVERY rank issues the broadcast of b+1 on P -- while U still runs update b.
+           Every rank issues the collectives in the same order (b = 0, 1, 2, ...); buffers are double-buffered by parity."""
+        n, ld, ops = self.n, self.ld, self.ops
+        gpu = self.device.type == "cuda"
+        if gpu:
+            U, P = ops.make_streams(self.device)
+            cur = torch.cuda.current_stream(self.device)
+            U.wait_stream(cur)
+            P.wait_stream(cur)
+        else:
+            U = P = None
+
+        class _On:  # `with _On(stream):` = torch stream context + library stream; a no-op on the CPU stand-in
+            def __init__(s2, st): s2.st = st
+            def __enter__(s2):
+                if gpu:
+                    s2.ctx = torch.cuda.stream(s2.st); s2.ctx.__enter__(); ops.use(s2.st)
+            def __exit__(s2, *a):
+                if gpu:
+                    s2.ctx.__exit__(*a)
+
+        def record(st):
+            return st.record_event() if gpu else None
+
+        def wait(st, ev):
+            if gpu and ev is not None:
+                st.wait_event(ev)
+
+        self.info = 0
+        with _On(U):
+            self.info_dev.zero_()
+            if not self.pivot:
+                self.ipiv.copy_(torch.arange(1, n + 1, dtype=torch.int64, device=self.device))
+        ev0 = record(U)
+        wait(P, ev0)
+        nb = len(self.layout)
+        recv = [None] * nb
+        done = [None] * nb
+
+        def produce(b, ev_ready):
+            """On P: factor (owner) + broadcast (everybody) block column b into buffer b % 2."""
+            j0, w, owner, lc = self.layout[b]
+            rows = n - j0
+            pb, mt = self.pbuf[b % 2], self.meta[b % 2]
+            panel = pb[: rows * w].view(rows, w)
+            with _On(P):
+                if b >= 2:
+                    wait(P, done[b - 2])          # the buffer was last read by update b-2
+                if self.rank == owner:
+                    wait(P, ev_ready)             # this rank's slice has received update b-1
+                    if b >= 1 and (rows + 511) // 512 > 32:
+                        # a panel taller than 32 workgroups does not fit next to the CU-masked update stream (32 CUs are
+                        # kept free): let the bulk update drain first instead of spinning for co-residency
+                        wait(P, done[b - 1])
+                    info = ops.panel(self.R, ld, n, j0, lc, w, self.ipiv, self.pivot)
+                    panel.copy_(self.R[j0:, lc:lc + w])
+                    mt[:w].copy_(self.ipiv[j0:j0 + w])
+                    mt[w] = info
+                if self.collective:
+                    src = owner if self.group is None else dist.get_global_rank(self.group, owner)
+                    dist.broadcast(panel, src=src, group=self.group)
+                    dist.broadcast(mt[: w + 1], src=src, group=self.group)
+                recv[b] = record(P)
+
+        produce(0, ev0)
+        for b in range(nb):
+            j0, w, owner, lc = self.layout[b]
+            pb, mt = self.pbuf[b % 2], self.meta[b % 2]
+            left_end, right_start = self._local_ranges(j0, w, owner, lc)
+            nxt_slice = 0
+            ev_ready = None
+            with _On(U):
+                wait(U, recv[b])
+                if self.rank != owner:
+                    self.ipiv[j0:j0 + w].copy_(mt[:w])
+                self.info_dev.copy_(torch.where(self.info_dev == 0, mt[w], self.info_dev))
+                if b + 1 < nb and self.rank == self.layout[b + 1][2]:
+                    # this rank owns block column b+1: bring exactly those columns up to date first
+                    nxt_slice = self.layout[b + 1][1]
+                    assert self.layout[b + 1][3] == right_start
+                    self._update(j0, w, pb, right_start, nxt_slice)
+                    ev_ready = record(U)
+                # the bulk of update b is queued BEFORE the (host-blocking) panel call below, so the two overlap on the GPU
+                if self.pivot:
+                    ops.laswp(self.R, ld, n, 0, left_end, self.ipiv, j0, j0 + w)
+                self._update(j0, w, pb, right_start + nxt_slice, self.n_loc - right_start - nxt_slice)
+                done[b] = record(U)
+            if b + 1 < nb:
+                produce(b + 1, ev_ready)
+        if gpu:
+            cur.wait_stream(U)
+            cur.wait_stream(P)
+            ops.use(None)
         self.info = int(self.info_dev.item())
         return self.info
 

@@ -59,7 +59,9 @@ class NumpyOps:
         _view(R, c0, m, w, ld)[:] = blk
 
 
-def _worker(rank, world, port, n, block, pivot, diag_add, q):
+def _worker(rank, world, port, n, block, pivot, diag_add, q, sync=False):
+    if sync:
+        os.environ["RFLU_DIST_SYNC"] = "1"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -84,12 +86,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n,block,pivot", [(2, 300, 64, True), (3, 257, 64, True), (2, 200, 128, False)])
-def test_block_column_lu_matches_single_process(world, n, block, pivot):
+@pytest.mark.parametrize("world,n,block,pivot,sync", [(2, 300, 64, True, False), (3, 257, 64, True, False),
+                                                      (2, 200, 128, False, False), (2, 300, 64, True, True)])
+def test_block_column_lu_matches_single_process(world, n, block, pivot, sync):
+    # sync=False: the lookahead schedule (panel b+1 factored and broadcast while update b is still queued);
+    # sync=True : one block column at a time.  Same collectives in the same order on every rank in both.
     diag_add = 0.0 if pivot else 10.0
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, block, pivot, diag_add, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, block, pivot, diag_add, q, sync))
              for port in [_free_port()] for r in range(world)]
     for p in procs:
         p.start()

@@ -88,7 +88,11 @@ struct Gran<double> {
 template <>
 struct Gran<float> {
     static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, float v) {
-        const u2v x = {__float_as_uint(v), tag};
+        unsigned bits = __float_as_uint(v);
+        // opaque to the optimiser: otherwise {a[j], tag} is built from a <2 x i32> load of (a[j], a[j+1]) out of the row
+        // array, and those overlapping vector loads keep the whole row in scratch memory instead of registers
+        asm volatile("" : "+v"(bits));
+        const u2v x = {bits, tag};
         __builtin_amdgcn_raw_buffer_store_b64(x, r, off, 0, AUX_SC1);
     }
     static __device__ __forceinline__ bool load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, float& v) {

@@ -137,7 +137,9 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
         T* Bs = As + G_BM * G_SA;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            As[a_row * G_SA + a_kb + e] = -ra[e];  // the accumulators start from C, so the products enter negated
+            // C_FIRST: the accumulators start as C itself (loaded straight into them, no dependent VALU before the first
+            // slab), so the products must enter negated; otherwise plain A and the subtraction happens in the epilogue
+            As[a_row * G_SA + a_kb + e] = C_FIRST ? -ra[e] : ra[e];
             Bs[b_k * G_SB + b_jb + e] = rb[e];
         }
     };
@@ -188,7 +190,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
         __syncthreads();
     }
 
-    // ---- epilogue: C = C_in - A*B (the products were accumulated negated)
+    // ---- epilogue: C = C_in - A*B   (C_FIRST: acc already holds it)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int col = n0 + wc * 64 + j * 16 + (lane & 15);
-                    if (col < g.N) crow_p[j * 16] = C_FIRST ? acc[i][j][r] : crow_p[j * 16] + acc[i][j][r];
+                    if (col < g.N) crow_p[j * 16] = C_FIRST ? acc[i][j][r] : crow_p[j * 16] - acc[i][j][r];
                 }
             }
         }

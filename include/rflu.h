@@ -88,6 +88,25 @@ int rflu_getrf_f64_dev(rflu_handle_t handle, int64_t m, int64_t n, double* A_dev
 int rflu_getrf_f32_dev(rflu_handle_t handle, int64_t m, int64_t n, float* A_dev, int64_t lda, int64_t* ipiv_dev,
                        int pivot, int64_t blocksize, int64_t* info);
 
+/* ---- the solve step that follows the path in every caller: ldiv!(F::LU, B), i.e. B <- U^-1 L^-1 P B ----
+ * Reference: stdlib ldiv!(::LU) on the object lu! returns (LinearSolve's solve!), and the package's own ldiv! for
+ * NotIPIV factors (src/lu.jl:60-64).  F/ipiv exactly as rflu_getrf_* left them (column-major packed L\U, 1-based
+ * ipiv; ipiv == NULL plays NotIPIV); B is n x nrhs column-major, overwritten with the solution.  A singular U
+ * (info != 0) yields Inf/NaN like LAPACK getrs; the host glue checks info first. */
+int rflu_getrs_f64(rflu_handle_t handle, int64_t n, int64_t nrhs, const double* F_host, int64_t lda,
+                   const int64_t* ipiv_host, double* B_host, int64_t ldb);
+int rflu_getrs_f32(rflu_handle_t handle, int64_t n, int64_t nrhs, const float* F_host, int64_t lda,
+                   const int64_t* ipiv_host, float* B_host, int64_t ldb);
+int rflu_getrs_f64_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, const double* F_dev, int64_t lda,
+                       const int64_t* ipiv_dev, double* B_dev, int64_t ldb);
+int rflu_getrs_f32_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, const float* F_dev, int64_t lda,
+                       const int64_t* ipiv_dev, float* B_dev, int64_t ldb);
+/* same on row-major device data (F as left by rflu_getrf_rm_*; B is n x nrhs row-major with leading dimension ldb) */
+int rflu_getrs_rm_f64_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, const double* R_dev, int64_t ld,
+                          const int64_t* ipiv_dev, double* B_dev, int64_t ldb);
+int rflu_getrs_rm_f32_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, const float* R_dev, int64_t ld,
+                          const int64_t* ipiv_dev, float* B_dev, int64_t ldb);
+
 /* ---- building blocks on the INTERNAL row-major layout: element (i,j) at R[i*ld + j] (device pointers).
  * These are the four kernels of the path plus the bookkeeping the multi-GPU block-column driver and the parity
  * tests need.  Pivot rows are GLOBAL 0-based row positions r0.. of the slab; ipiv entries are 1-based rows.

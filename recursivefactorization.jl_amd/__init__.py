@@ -16,12 +16,13 @@ from .lu import (  # noqa: F401
     Transpose,
     Val,
     last_path,
+    ldiv_,
     lu,
     lu_,
     normalize_pivot,
 )
 
 __all__ = [
-    "lu", "lu_", "LU", "NotIPIV", "RowMaximum", "NoPivot", "Val", "Adjoint", "Transpose", "SingularException",
+    "lu", "lu_", "ldiv_", "LU", "NotIPIV", "RowMaximum", "NoPivot", "Val", "Adjoint", "Transpose", "SingularException",
     "normalize_pivot", "last_path", "Handle", "RfluError", "default_handle", "NOPIVOT_NEGATIVE_INFO",
 ]

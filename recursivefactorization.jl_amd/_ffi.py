@@ -27,6 +27,9 @@ _TYPED = {
     "rflu_getrf_{s}": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_int, c_i64, c_p]),
     "rflu_getrf_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_int, c_i64, c_p]),
     "rflu_getrf_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_int, c_i64, c_p]),
+    "rflu_getrs_{s}": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_i64]),
+    "rflu_getrs_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_i64]),
+    "rflu_getrs_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_i64]),
     "rflu_panel_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_int, c_p]),
     "rflu_laswp_rm_{s}_dev": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64]),
     "rflu_trsm_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64]),

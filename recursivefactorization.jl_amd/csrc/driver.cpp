@@ -98,6 +98,89 @@ static int trsm_public(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t l
     return trsm_rec<T>(h, n, nrhs, L, ldl, B, ldb, li);
 }
 
+// ---- B <- U^-1 B (upper, non-unit) by recursive splitting on 64-row boundaries: bottom block, GEMM, top block ------
+template <typename T>
+static int triu_solve_rec(Handle* h, int64_t n, int64_t nrhs, const T* U, int64_t ldu, T* B, int64_t ldb)
+{
+    if (n <= 0 || nrhs <= 0) return RFLU_OK;
+    if (n <= NB) return launch_triu_base<T>(h, n, nrhs, U, ldu, B, ldb);
+    const int64_t leaves = (n + NB - 1) / NB;
+    const int64_t n1 = ((leaves + 1) / 2) * NB;  // rows of the top block; the (possibly partial) rest is the bottom
+    RFLU_TRY(triu_solve_rec<T>(h, n - n1, nrhs, U + n1 * ldu + n1, ldu, B + n1 * ldb, ldb));
+    RFLU_TRY(launch_gemm<T>(h, n1, nrhs, n - n1, U + n1, ldu, B + n1 * ldb, ldb, B, ldb));
+    return triu_solve_rec<T>(h, n1, nrhs, U, ldu, B, ldb);
+}
+
+// ldiv!(F::LU, B): B <- U^-1 L^-1 P B on row-major device data (F as left by getrf_rm; B is n x nrhs, row-major).
+template <typename T>
+static int getrs_rm(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, const int64_t* ipiv, T* B, int64_t ldb)
+{
+    if (n <= 0 || nrhs <= 0) return RFLU_OK;
+    RFLU_TRY(ensure_bookkeeping(h, n));
+    if (ipiv) {  // rows of B follow the factorization's interchanges (NULL = NotIPIV: nothing to apply)
+        RFLU_TRY(launch_perm_build(h, ipiv, 0, n, n));
+        RFLU_TRY(launch_laswp<T>(h, B, ldb, 0, nrhs, 0, (n + NB - 1) / NB));
+    }
+    RFLU_TRY(trsm_public<T>(h, n, nrhs, R, ld, B, ldb));
+    return triu_solve_rec<T>(h, n, nrhs, R, ld, B, ldb);
+}
+
+// column-major device entry: F (n x n, lda) and B (n x nrhs, ldb) as LinearAlgebra.LU / LAPACK getrs hold them
+template <typename T>
+static int getrs_cm_dev(Handle* h, int64_t n, int64_t nrhs, const T* F, int64_t lda, const int64_t* ipiv, T* B,
+                        int64_t ldb)
+{
+    if (n < 0 || nrhs < 0 || lda < std::max<int64_t>(n, 1) || ldb < std::max<int64_t>(n, 1)) {
+        set_error("getrs: bad arguments n=%lld nrhs=%lld lda=%lld ldb=%lld", (long long)n, (long long)nrhs,
+                  (long long)lda, (long long)ldb);
+        return RFLU_ERR_ARG;
+    }
+    if (n == 0 || nrhs == 0) return RFLU_OK;
+    const int64_t ldr = round_up(n, 16), ldx = round_up(nrhs, 16);
+    RFLU_TRY(ensure_buffer(&h->work, &h->work_bytes, (size_t)n * (size_t)ldr * sizeof(T)));
+    RFLU_TRY(ensure_buffer(&h->rhs_work, &h->rhs_work_bytes, (size_t)n * (size_t)ldx * sizeof(T)));
+    T* R = static_cast<T*>(h->work);
+    T* X = static_cast<T*>(h->rhs_work);
+    RFLU_TRY(launch_transpose<T>(h, n, n, F, lda, R, ldr));
+    RFLU_TRY(launch_transpose<T>(h, n, nrhs, B, ldb, X, ldx));
+    RFLU_TRY(getrs_rm<T>(h, n, nrhs, R, ldr, ipiv, X, ldx));
+    RFLU_TRY(launch_transpose<T>(h, nrhs, n, X, ldx, B, ldb));
+    RFLU_HIP(hipStreamSynchronize(h->stream));
+    return RFLU_OK;
+}
+
+template <typename T>
+static int getrs_host(Handle* h, int64_t n, int64_t nrhs, const T* F, int64_t lda, const int64_t* ipiv, T* B, int64_t ldb)
+{
+    if (n < 0 || nrhs < 0 || lda < std::max<int64_t>(n, 1) || ldb < std::max<int64_t>(n, 1) ||
+        (n > 0 && nrhs > 0 && (F == nullptr || B == nullptr))) {
+        set_error("getrs: bad arguments");
+        return RFLU_ERR_ARG;
+    }
+    if (n == 0 || nrhs == 0) return RFLU_OK;
+    RFLU_TRY(ensure_buffer(&h->hostA_dev, &h->hostA_bytes, (size_t)n * (size_t)n * sizeof(T)));
+    RFLU_TRY(ensure_buffer(&h->hostB_dev, &h->hostB_bytes, (size_t)n * (size_t)nrhs * sizeof(T)));
+    if ((size_t)n > h->ipiv_cap) {
+        if (h->ipiv_dev) RFLU_HIP(hipFree(h->ipiv_dev));
+        h->ipiv_dev = nullptr;
+        h->ipiv_cap = 0;
+        RFLU_HIP(hipMalloc((void**)&h->ipiv_dev, (size_t)n * sizeof(int64_t)));
+        h->ipiv_cap = (size_t)n;
+    }
+    T* dF = static_cast<T*>(h->hostA_dev);
+    T* dB = static_cast<T*>(h->hostB_dev);
+    RFLU_HIP(hipMemcpy2DAsync(dF, (size_t)n * sizeof(T), F, (size_t)lda * sizeof(T), (size_t)n * sizeof(T), (size_t)n,
+                              hipMemcpyHostToDevice, h->stream));
+    RFLU_HIP(hipMemcpy2DAsync(dB, (size_t)n * sizeof(T), B, (size_t)ldb * sizeof(T), (size_t)n * sizeof(T), (size_t)nrhs,
+                              hipMemcpyHostToDevice, h->stream));
+    if (ipiv) RFLU_HIP(hipMemcpyAsync(h->ipiv_dev, ipiv, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    RFLU_TRY(getrs_cm_dev<T>(h, n, nrhs, dF, n, ipiv ? h->ipiv_dev : nullptr, dB, n));
+    RFLU_HIP(hipMemcpy2DAsync(B, (size_t)ldb * sizeof(T), dB, (size_t)n * sizeof(T), (size_t)n * sizeof(T), (size_t)nrhs,
+                              hipMemcpyDeviceToHost, h->stream));
+    RFLU_HIP(hipStreamSynchronize(h->stream));
+    return RFLU_OK;
+}
+
 template <typename T>
 struct Fact {
     Handle* h;
@@ -453,6 +536,8 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->work) (void)hipFree(h->work);
     if (h->ipiv_dev) (void)hipFree(h->ipiv_dev);
     if (h->hostA_dev) (void)hipFree(h->hostA_dev);
+    if (h->rhs_work) (void)hipFree(h->rhs_work);
+    if (h->hostB_dev) (void)hipFree(h->hostB_dev);
     if (h->pm_cnt) (void)hipFree(h->pm_cnt);
     if (h->pm_dst) (void)hipFree(h->pm_dst);
     if (h->pm_src) (void)hipFree(h->pm_src);
@@ -569,6 +654,26 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out)
     {                                                                                                                 \
         CHECK_HANDLE(handle);                                                                                         \
         return launch_transpose<T>(H(handle), n, m, R, ldr, A, lda);                                                  \
+    }                                                                                                                 \
+    int rflu_getrs_##SFX(rflu_handle_t handle, int64_t n, int64_t nrhs, const T* F, int64_t lda, const int64_t* ipiv,  \
+                         T* B, int64_t ldb)                                                                           \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        return getrs_host<T>(H(handle), n, nrhs, F, lda, ipiv, B, ldb);                                               \
+    }                                                                                                                 \
+    int rflu_getrs_##SFX##_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, const T* F, int64_t lda,                \
+                               const int64_t* ipiv, T* B, int64_t ldb)                                                \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        return getrs_cm_dev<T>(H(handle), n, nrhs, F, lda, ipiv, B, ldb);                                             \
+    }                                                                                                                 \
+    int rflu_getrs_rm_##SFX##_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, const T* R, int64_t ld,              \
+                                  const int64_t* ipiv, T* B, int64_t ldb)                                             \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        RFLU_TRY(getrs_rm<T>(H(handle), n, nrhs, R, ld, ipiv, B, ldb));                                               \
+        RFLU_HIP(hipStreamSynchronize(H(handle)->stream));                                                            \
+        return RFLU_OK;                                                                                               \
     }                                                                                                                 \
     int rflu_fill_uniform_##SFX##_dev(rflu_handle_t handle, T* A, int64_t m, int64_t n, int64_t ld, int row_major,    \
                                       uint64_t seed, int64_t M_global, int64_t i0, int64_t j0, double diag_add)       \

@@ -63,6 +63,10 @@ struct Handle {
     size_t ipiv_cap = 0;
     void* hostA_dev = nullptr;   // device copy of the host matrix (host entry points)
     size_t hostA_bytes = 0;
+    void* rhs_work = nullptr;    // row-major copy of the right-hand sides (getrs)
+    size_t rhs_work_bytes = 0;
+    void* hostB_dev = nullptr;   // device copy of host right-hand sides (getrs host entry)
+    size_t hostB_bytes = 0;
 
     // pivot bookkeeping: for every chunk of NB pivots the list of (dst,src) row moves equivalent to its interchanges
     int* pm_cnt = nullptr;
@@ -120,6 +124,8 @@ int launch_trsm_base(Handle* h, int64_t nb, int64_t nrhs, const T* L, int64_t ld
 // fused strip TRSM (n <= 256) on pre-inverted 64x64 diagonal blocks, and the batched inversion of those blocks
 template <typename T>
 int launch_trsm_fused(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t ldl, const T* Linv, T* B, int64_t ldb);
+template <typename T>
+int launch_triu_base(Handle* h, int64_t nb, int64_t nrhs, const T* U, int64_t ldu, T* B, int64_t ldb);
 template <typename T>
 int launch_diag_inv(Handle* h, int64_t n, const T* L, int64_t ldl, T* Linv);
 template <typename T>

@@ -213,4 +213,73 @@ template int launch_diag_inv<float>(Handle*, int64_t, const float*, int64_t, flo
 template int launch_trsm_fused<double>(Handle*, int64_t, int64_t, const double*, int64_t, const double*, double*, int64_t);
 template int launch_trsm_fused<float>(Handle*, int64_t, int64_t, const float*, int64_t, const float*, float*, int64_t);
 
+
+// =====================================================================================================================
+// Upper-triangular (non-unit) solve  B <- U^-1 B  -- the second leg of ldiv!(F::LU, B) (SURVEY.md 8f "next" row 1:
+// the reference's own ldiv! for NotIPIV, /root/reference/src/lu.jl:60-64, and stdlib getrs for pivoted factors).
+// Host recursion in driver.cpp (triu_solve_rec): bottom block first, GEMM update of the rows above, then the top block;
+// this kernel is the <= 64-row base: one thread per right-hand-side column, back substitution in registers, U in LDS.
+// =====================================================================================================================
+template <typename T, int I>
+struct TriuRow {
+    static __device__ __forceinline__ void run(const T* sU, T (&x)[NB])
+    {
+        if constexpr (I >= 0) {
+            T acc[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+            for (int k = I + 1; k < NB; ++k) acc[k & 3] += sU[I * NB + k] * x[k];
+            T s = (x[I] - ((acc[0] + acc[1]) + (acc[2] + acc[3]))) / sU[I * NB + I];
+            asm volatile("" : "+v"(s) : : "memory");
+            x[I] = s;
+            TriuRow<T, I - 1>::run(sU, x);
+        }
+    }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(128) triu_base_kernel(int nb, int64_t nrhs, const T* __restrict__ U, int64_t ldu,
+                                                        T* __restrict__ B, int64_t ldb)
+{
+    __shared__ T sU[NB * NB];
+    const int tid = threadIdx.x;
+    {
+        T tmp[NB * NB / 128];
+#pragma unroll
+        for (int it = 0; it < NB * NB / 128; ++it) {
+            const int idx = it * 128 + tid;
+            const int i = idx >> 6, k = idx & 63;
+            // rows/columns beyond nb behave like an identity block
+            tmp[it] = (i < nb && k < nb) ? (k >= i ? U[(int64_t)i * ldu + k] : T(0)) : (i == k ? T(1) : T(0));
+        }
+#pragma unroll
+        for (int it = 0; it < NB * NB / 128; ++it) sU[it * 128 + tid] = tmp[it];
+    }
+    const int64_t j = (int64_t)blockIdx.x * 128 + tid;
+    T x[NB];
+    if (j < nrhs) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) x[i] = (i < nb) ? B[(int64_t)i * ldb + j] : T(0);
+    }
+    __syncthreads();
+    if (j >= nrhs) return;
+    TriuRow<T, NB - 1>::run(sU, x);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        if (i < nb) B[(int64_t)i * ldb + j] = x[i];
+}
+
+template <typename T>
+int launch_triu_base(Handle* h, int64_t nb, int64_t nrhs, const T* U, int64_t ldu, T* B, int64_t ldb)
+{
+    if (nb <= 0 || nrhs <= 0) return RFLU_OK;
+    if (nb > NB) { set_error("launch_triu_base: block of %lld rows exceeds %d", (long long)nb, NB); return RFLU_ERR_ARG; }
+    ProfScope ps(h, RFLU_K_TRSM, (double)nb * (double)nb * (double)nrhs);
+    const unsigned grid = (unsigned)((nrhs + 127) / 128);
+    hipLaunchKernelGGL(triu_base_kernel<T>, dim3(grid), dim3(128), 0, h->stream, (int)nb, nrhs, U, ldu, B, ldb);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+template int launch_triu_base<double>(Handle*, int64_t, int64_t, const double*, int64_t, double*, int64_t);
+template int launch_triu_base<float>(Handle*, int64_t, int64_t, const float*, int64_t, float*, int64_t);
+
 }  // namespace rflu

@@ -7,6 +7,7 @@ Reference interface mirrored (citations into /root/reference/src/lu.jl):
     normalize_pivot: Val(true)/RowMaximum(), Val(false)/NoPivot()                  :10-17   -> ``pivot`` accepts both
     NotIPIV (lazy identity pivots for NoPivot)                                     :27-40   -> ``NotIPIV``
     LU(A, ipiv, info), checknonsingular(info) -> SingularException                 :128-129 -> ``LU``, ``SingularException``
+    ldiv!(F, B) (stdlib for pivoted LU; the package's own for NotIPIV)             :60-64   -> ``ldiv_``
     NoPivot failures carry a NEGATIVE info on Julia >= 1.11                        :25,250,324 -> ``NOPIVOT_NEGATIVE_INFO``
     Adjoint/Transpose wrappers                                                     :85-87   -> ``Adjoint`` / ``lu(A.T ...)``
 
@@ -250,6 +251,59 @@ def lu(A, pivot=True, thread=False, **kwargs) -> LU:
     else:
         C = np.array(A, order="F", copy=True)
     return lu_(C, None, pivot, thread, **kwargs)
+
+
+def ldiv_(F: LU, B, *, handle=None):
+    """``ldiv!(F, B)``: overwrite ``B`` (a vector or an n x k matrix) with ``A \\ B`` using the factorization ``F``.
+
+    Mirrors stdlib ``ldiv!(::LU, B)`` on the object ``lu!`` returns -- what LinearSolve's ``solve!`` calls right after the
+    factorization -- and the package's own ``ldiv!`` for ``NotIPIV`` factors (/root/reference/src/lu.jl:60-64; tested at
+    test/runtests.jl:21-28, 116-128).  Served by ``rflu_getrs_*`` (interchanges, fused unit-lower TRSM, upper solve).
+    Raises ``SingularException`` when ``F.info != 0`` (the solve would divide by an exactly zero pivot).
+    """
+    if isinstance(F, Adjoint):
+        raise NotImplementedError("solve with the adjoint factorization is not part of the MI355X path")
+    if F.info != 0:
+        raise SingularException(abs(F.info))
+    A = F.factors
+    n = int(A.shape[0])
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("ldiv! needs a square factorization")
+    if B.shape[0] != n:
+        raise ValueError("right-hand side has the wrong number of rows")
+    nrhs = 1 if B.ndim == 1 else int(B.shape[1])
+    nopiv = isinstance(F.ipiv, NotIPIV)
+    if _is_torch(A):
+        import torch
+
+        if not (_is_torch(B) and B.is_cuda and B.dtype == A.dtype):
+            raise TypeError("B must be a CUDA tensor of the factorization's dtype")
+        sfx = _sfx(A.dtype)
+        h = handle or _ffi.default_handle(A.device.index or 0)
+        h.set_stream(torch.cuda.current_stream(A.device).cuda_stream)
+        ip = ctypes.c_void_p(0 if nopiv else F.ipiv.data_ptr())
+        if A.stride(0) == 1:  # column-major factors -> column-major right-hand sides
+            if B.ndim == 2 and not (B.stride(0) == 1 and B.stride(1) >= n):
+                raise ValueError("B must be column-major like the factors")
+            ldb = n if B.ndim == 1 else B.stride(1)
+            h.call(f"rflu_getrs_{sfx}_dev", n, nrhs, ctypes.c_void_p(A.data_ptr()), A.stride(1), ip,
+                   ctypes.c_void_p(B.data_ptr()), ldb)
+        else:                 # row-major factors (rflu_getrf_rm) -> row-major right-hand sides
+            if B.ndim == 2 and B.stride(1) != 1:
+                raise ValueError("B must be row-major like the factors")
+            ldb = 1 if B.ndim == 1 else B.stride(0)
+            h.call(f"rflu_getrs_rm_{sfx}_dev", n, nrhs, ctypes.c_void_p(A.data_ptr()), A.stride(0), ip,
+                   ctypes.c_void_p(B.data_ptr()), ldb)
+        return B
+    if not (isinstance(B, np.ndarray) and B.dtype == A.dtype and (B.ndim == 1 and B.flags.c_contiguous or B.flags.f_contiguous)):
+        raise TypeError("B must be a column-major numpy array of the factorization's dtype")
+    sfx = _sfx(A.dtype)
+    h = handle or _ffi.default_handle(0)
+    h.set_stream(None)
+    ipiv = None if nopiv else np.ascontiguousarray(F.ipiv, dtype=np.int64)
+    h.call(f"rflu_getrs_{sfx}", n, nrhs, ctypes.c_void_p(A.ctypes.data), max(n, 1),
+           ctypes.c_void_p(0 if ipiv is None else ipiv.ctypes.data), ctypes.c_void_p(B.ctypes.data), max(n, 1))
+    return B
 
 
 def last_path(device: int = 0) -> str:

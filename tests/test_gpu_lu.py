@@ -216,3 +216,37 @@ def test_block_column_driver_single_rank_hip_ops(n, block, pivot):
     assert np.array_equal(job.ipiv.cpu().numpy(), ipo)
     assert np.max(np.abs(job.gather_factors() - Fo)) < 50 * tol_E(A)
     assert job.matvec_residual() < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [1, 8, 64, 65, 200, 300, 1000])
+def test_ldiv_solve_step(dtype, n):
+    # runtests.jl:21-28 (b = ldiv!(MF, A[:, end]) ~ e_n) and :116-128 (NotIPIV ldiv!, ||Ax-b|| < 1000*n*eps on rand + 10I)
+    eps = np.finfo(dtype).eps
+    A = rand_matrix(n, n, seed=500 + n, dtype=dtype)
+    F = rf.lu(A, True, check=False)
+    b = rf.ldiv_(F, A[:, -1].copy())
+    rhs = np.zeros(n); rhs[-1] = 1
+    if np.all(np.isfinite(b)):
+        assert np.allclose(b, rhs, atol=100 * 20 * n * eps * max(1.0, float(np.max(np.abs(F.factors)))), rtol=0)
+    D = (rand_matrix(n, n, seed=600 + n, dtype=dtype) + dtype(10) * np.eye(n, dtype=dtype)).astype(dtype, order="F")
+    for pivot in (rf.NoPivot(), rf.RowMaximum()):
+        G = rf.lu(D, pivot)
+        v = rand_matrix(n, 1, seed=700 + n, dtype=dtype)[:, 0].copy()
+        x = rf.ldiv_(G, v.copy())
+        assert x.dtype == dtype and np.linalg.norm(D.astype(np.float64) @ x - v) < 1000 * n * eps
+        B3 = rand_matrix(n, 3, seed=800 + n, dtype=dtype).copy(order="F")
+        X = rf.ldiv_(G, B3.copy(order="F"))
+        assert np.linalg.norm(D.astype(np.float64) @ X - B3) < 1000 * n * eps
+    # device-resident, column-major and row-major
+    dF = rf.lu_(to_dev_cm(D), None, True)
+    dB = to_dev_cm(B3)
+    rf.ldiv_(dF, dB)
+    assert np.linalg.norm(D.astype(np.float64) @ dB.cpu().numpy() - B3) < 1000 * n * eps
+    rF = rf.lu_(torch.from_numpy(np.ascontiguousarray(D)).to("cuda:0"), None, True)
+    rB = torch.from_numpy(np.ascontiguousarray(B3)).to("cuda:0")
+    rf.ldiv_(rF, rB)
+    assert np.linalg.norm(D.astype(np.float64) @ rB.cpu().numpy() - B3) < 1000 * n * eps
+    S = D.copy(); S[:, n // 2] = 0
+    with pytest.raises(rf.SingularException):
+        rf.ldiv_(rf.lu(S, True, check=False), v.copy())

@@ -238,50 +238,74 @@ static int get_event(Handle* h, size_t idx, hipEvent_t* ev)
     return RFLU_OK;
 }
 
-// The update stream leaves `reserve` CUs (a multiple of 32) to the critical-path stream so that the cooperative panel
-// kernel (one 512-thread workgroup per CU) finds all its workgroups a home at once.
-int ensure_ustream(Handle* h, int reserve)
+// An update stream leaves `reserve` CUs (a multiple of 32, 32..224) to the critical-path stream so that the cooperative
+// panel kernel (one 512-thread workgroup per CU) finds all its workgroups a home at once.  Streams are created once per
+// reservation and kept for the life of the handle.
+int get_ustream(Handle* h, int reserve, hipStream_t* out)
 {
-    if (h->ustream && h->ustream_reserve == reserve) return RFLU_OK;
-    if (h->ustream) { RFLU_HIP(hipStreamSynchronize(h->ustream)); RFLU_HIP(hipStreamDestroy(h->ustream)); h->ustream = nullptr; }
-    // CU mask bits are enumerated round-robin over the 8 XCDs (scripts/probes/cumask.hip): bits 0..31 are 4 CUs of every
-    // XCD, and so on.  A mask that empties an XCD is ignored by the runtime, so whole 32-bit words are cleared.
-    uint32_t mask[8];
-    for (int i = 0; i < 8; ++i) mask[i] = (i < reserve / 32) ? 0u : 0xffffffffu;
-    if (hipExtStreamCreateWithCUMask(&h->ustream, 8, mask) != hipSuccess) {
-        (void)hipGetLastError();
-        RFLU_HIP(hipStreamCreateWithFlags(&h->ustream, hipStreamNonBlocking));
+    const int r = reserve / 32;
+    if (reserve % 32 != 0 || r < 1 || r > 7) { set_error("CU reservation %d not in 32..224 step 32", reserve); return RFLU_ERR_ARG; }
+    if (!h->ustreams[r]) {
+        // CU mask bits are enumerated round-robin over the 8 XCDs (scripts/probes/cumask.hip): bits 0..31 are 4 CUs of
+        // every XCD, and so on.  A mask that empties an XCD is ignored by the runtime, so whole 32-bit words are cleared.
+        uint32_t mask[8];
+        for (int i = 0; i < 8; ++i) mask[i] = (i < r) ? 0u : 0xffffffffu;
+        if (hipExtStreamCreateWithCUMask(&h->ustreams[r], 8, mask) != hipSuccess) {
+            (void)hipGetLastError();
+            RFLU_HIP(hipStreamCreateWithFlags(&h->ustreams[r], hipStreamNonBlocking));
+        }
     }
-    h->ustream_reserve = reserve;
+    *out = h->ustreams[r];
     return RFLU_OK;
 }
 
+// ---- cost model of the lookahead schedule (microseconds; calibrated on MI355X) ----
+static double model_panel_us(int64_t rows, int64_t W)
+{
+    const double G = double((rows + PANEL_THREADS - 1) / PANEL_THREADS);
+    const double step = 2.6 + 0.025 * G;                      // one pivot step of the cooperative kernel
+    return double(W) * step + double(W) / NB * 70.0           // + per-leaf interchanges / solves / launches
+           + double(rows) * double(W) * double(W) / 30e6;     // + the recursion's own GEMMs (small K, ~30 TFLOP/s)
+}
+static double model_gemm_flops_per_us(int64_t K, int cus, size_t elem)
+{
+    const double tf = (K >= 2048 ? 64.0 : K >= 1024 ? 60.0 : K >= 512 ? 55.0 : 50.0) * (elem == 4 ? 1.6 : 1.0);
+    return tf * 1e6 * double(cus) / 256.0;
+}
+
 // Right-looking over block columns of width W with one block column of lookahead (two streams).
-//   P (h->stream, all CUs): panel_b -> evP[b] -> [wait evU1[b-1]] next_b (update of block column b+1) -> panel_{b+1} ...
-//   U (h->ustream, 224 CUs): [wait evP[b]] left swaps_b -> rest_b.part1 (block column b+2) -> evU1[b] -> rest_b.part2
+//   P (h->stream, all CUs)      : panel_b -> restB_{b-1} -> evP[b] -> [wait evU1[b-1]] next_b (update of block column b+1)
+//                                 -> panel_{b+1} ...
+//   U (CU-masked update stream) : [wait evP[b]] left swaps_b -> rest_b.part1 (block column b+2) -> evU1[b] -> restA_b
+// rest_b (the update of everything right of block column b+1) is split by columns: restA_b is sized by the cost model to
+// take as long as P's next_b + panel_{b+1}, and runs next to them on the CUs the mask leaves it; what does not fit in
+// that time (restB_b: the early, update-bound block columns and every tall panel) follows panel_{b+1} on P with the
+// whole GPU.  The mask reserves ceil(panel workgroups / 32) * 32 CUs, chosen per block column.
 // Every block column receives the same operations in the same order as in the recursion; only independent pieces
 // overlap in time, so the factors are those of the one-stream path.
 template <typename T>
 static int factor_lookahead(Fact<T>& f, int64_t W)
 {
     Handle* h = f.h;
-    {
-        int reserve = 32;
-        if (const char* e = getenv("RFLU_RESERVE_CUS")) {  // tuning knob: CUs kept away from the update stream
-            const int v = atoi(e);
-            if (v >= 32 && v <= 224 && v % 32 == 0) reserve = v;
-        }
-        RFLU_TRY(ensure_ustream(h, reserve));
+    int min_reserve = 32;
+    double split_scale = 1.0;
+    const bool split_all = getenv("RFLU_SPLIT_ALL") != nullptr;
+    double split_share = 0.5;   // tuning knob: how much of what is left after the modelled time stays on the update stream
+    if (const char* e = getenv("RFLU_SPLIT_SHARE")) split_share = atof(e);
+    int max_reserve = 64;       // taller panels (> 64 workgroups) take too many CUs from the update: one stream instead
+    if (const char* e = getenv("RFLU_MAX_RESERVE")) max_reserve = atoi(e);
+    if (const char* e = getenv("RFLU_RESERVE_CUS")) {  // tuning knob: least number of CUs kept away from the update stream
+        const int v = atoi(e);
+        if (v >= 32 && v <= 224 && v % 32 == 0) min_reserve = v;
     }
-    hipStream_t P = h->stream, U = h->ustream;
+    if (const char* e = getenv("RFLU_SPLIT_SCALE")) {  // tuning knob: scales the modelled critical-path time (0 = no split)
+        split_scale = atof(e);
+    }
+    hipStream_t P = h->stream;
     const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
     T* R = f.R;
     const int64_t nblk = (mn + W - 1) / W;
     hipEvent_t ev;
-    // U must not start before everything already queued on P (layout change, info reset) is done
-    RFLU_TRY(get_event(h, 0, &ev));
-    RFLU_HIP(hipEventRecord(ev, P));
-    RFLU_HIP(hipStreamWaitEvent(U, ev, 0));
 
     auto update = [&](hipStream_t st, int64_t j0, int64_t jb, int64_t c0, int64_t c1) -> int {
         // apply block column [j0, j0+jb) to columns [c0, c1): interchanges, block-row solve, Schur update
@@ -298,22 +322,56 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
         return rc;
     };
 
+    // events: 4b+1 = evP[b], 4b+2 = evU1[b], 4b+3 = evUend[b]
+    hipStream_t Uprev = nullptr;      // update stream of the previous overlapped block column
+    int64_t uend_prev = -1;           // its block index (evUend recorded), -1: none
+    bool prev_overlapped = false;
+    struct { bool valid = false; int64_t j0 = 0, jb = 0, c0 = 0; int64_t need_uend = -1; } pend;  // restB of block b-1
+
+    auto flush_pending = [&]() -> int {
+        if (!pend.valid) return RFLU_OK;
+        if (pend.need_uend >= 0) {  // its columns were last written by restA of the block column before
+            hipEvent_t e2;
+            RFLU_TRY(get_event(h, 4 * pend.need_uend + 3, &e2));
+            RFLU_HIP(hipStreamWaitEvent(P, e2, 0));
+        }
+        pend.valid = false;
+        return update(P, pend.j0, pend.jb, pend.c0, n);
+    };
+
     for (int64_t b = 0; b < nblk; ++b) {
         const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
         // ---- panel b on P: Toledo recursion on the block column, interchanges confined to its own columns ----
         f.sw_lo = j0;
         f.sw_hi = je;
         RFLU_TRY(f.rec(j0, je));
-        // A panel taller than 32 workgroups would need more than the 32 CUs kept free for it, and at that height the
-        // trailing update dwarfs the panel anyway (GEMM-bound): run such block columns on one stream, whole GPU each.
-        if ((m - j0 + PANEL_THREADS - 1) / PANEL_THREADS > h->ustream_reserve) {
+        RFLU_TRY(flush_pending());                                   // restB_{b-1}: whole GPU, after the panel
+        // the panel that will run next to this block column's update is panel b+1
+        const int64_t rows_next = m - je;
+        const int64_t g_next = (rows_next + PANEL_THREADS - 1) / PANEL_THREADS;
+        const int reserve = std::max<int>(min_reserve, int((std::max<int64_t>(g_next, 1) + 31) / 32 * 32));
+        if (reserve > std::min(max_reserve, 224)) {
+            // the next panel needs (almost) the whole GPU: run this block column on one stream
+            if (uend_prev >= 0) {
+                RFLU_TRY(get_event(h, 4 * uend_prev + 3, &ev));
+                RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
+                uend_prev = -1;
+            }
             if (f.pivot && j0 > 0) RFLU_TRY(launch_laswp<T>(h, R, ld, 0, j0, j0 / NB, (je + NB - 1) / NB));
             RFLU_TRY(update(P, j0, jb, je, n));
+            prev_overlapped = false;
+            Uprev = nullptr;
             continue;
         }
-        RFLU_TRY(get_event(h, 1 + 3 * b, &ev));
+        hipStream_t U;
+        RFLU_TRY(get_ustream(h, reserve, &U));
+        RFLU_TRY(get_event(h, 4 * b + 1, &ev));
         RFLU_HIP(hipEventRecord(ev, P));
         RFLU_HIP(hipStreamWaitEvent(U, ev, 0));
+        if (Uprev && Uprev != U && uend_prev >= 0) {                 // a different mask: order the two update streams
+            RFLU_TRY(get_event(h, 4 * uend_prev + 3, &ev));
+            RFLU_HIP(hipStreamWaitEvent(U, ev, 0));
+        }
         // ---- U: interchanges on the finished columns to the left ----
         if (f.pivot && j0 > 0) {
             hipStream_t saved = h->stream;
@@ -322,30 +380,67 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
             h->stream = saved;
             RFLU_TRY(rc);
         }
-        if (je >= n) break;
+        if (je >= n) {
+            RFLU_TRY(get_event(h, 4 * b + 3, &ev));
+            RFLU_HIP(hipEventRecord(ev, U));
+            uend_prev = b;
+            Uprev = U;
+            break;
+        }
         const int64_t n1e = std::min(je + W, n);                                            // end of block column b+1
         const int64_t n2e = std::min(n1e + W, n);                                           // end of block column b+2
         // ---- P: next block column (needs rest_{b-1}.part1, which updated exactly these columns).  Handing all but its
         // first leaf to U (and gating P's second leaf on it) was measured slower: U's in-order queue is still busy with
         // rest_{b-1} in the early, update-bound block columns.
-        if (b > 0) {
-            RFLU_TRY(get_event(h, 3 + 3 * (b - 1), &ev));
+        if (b > 0 && prev_overlapped) {
+            RFLU_TRY(get_event(h, 4 * (b - 1) + 2, &ev));
             RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
         }
         RFLU_TRY(update(P, j0, jb, je, n1e));
-        // ---- U: block column b+2 first (the next `next`), then everything further right ----
+        // ---- U: block column b+2 first (the next `next`), then as much of the rest as fits next to P's work ----
         RFLU_TRY(update(U, j0, jb, n1e, n2e));
-        RFLU_TRY(get_event(h, 3 + 3 * b, &ev));
+        RFLU_TRY(get_event(h, 4 * b + 2, &ev));
         RFLU_HIP(hipEventRecord(ev, U));
-        RFLU_TRY(update(U, j0, jb, n2e, n));
+        int64_t cA = n;                                                                      // restA = [n2e, cA)
+        // With the minimal reservation the masked stream keeps 7/8 of the GPU and a split cannot win more than ~1 %
+        // (measured: nothing); it pays for the tall panels, whose reservation takes a quarter to half of the CUs.
+        if (split_scale > 0 && m > je && (reserve > 32 || split_all)) {
+            const double rateU = model_gemm_flops_per_us(jb, 256 - reserve, sizeof(T));
+            const double rateP = model_gemm_flops_per_us(jb, 256, sizeof(T));
+            const double col_flops = 2.0 * double(m - je) * double(jb);                      // per trailing column
+            const double tP = split_scale * ((je < mn ? model_panel_us(m - je, std::min(W, mn - je)) : 0.0)
+                                             + col_flops * double(n1e - je) / rateP);
+            const double colsA = tP * rateU / col_flops;                                     // columns U finishes in tP
+            const int64_t left = n - n1e;
+            // what is left after tP is shared by both streams; below one GEMM tile column it is not worth a launch
+            int64_t a = int64_t(colsA) / 128 * 128;
+            a = std::max<int64_t>(a, n2e - n1e);
+            if (left - a >= 512)
+                cA = n1e + a + int64_t(split_share * double(left - a) * double(256 - reserve) / 512.0) / 128 * 128;
+        }
+        RFLU_TRY(update(U, j0, jb, n2e, cA));
+        RFLU_TRY(get_event(h, 4 * b + 3, &ev));
+        RFLU_HIP(hipEventRecord(ev, U));
+        if (cA < n) {
+            pend.valid = true;
+            pend.j0 = j0;
+            pend.jb = jb;
+            pend.c0 = cA;
+            pend.need_uend = uend_prev;   // restA_{b-1} may have written columns right of cA
+        }
+        uend_prev = b;
+        Uprev = U;
+        prev_overlapped = true;
     }
+    RFLU_TRY(flush_pending());
     f.sw_lo = 0;
     f.sw_hi = -1;
     f.gate = nullptr;
     // join: P continues only after U has drained
-    RFLU_TRY(get_event(h, 0, &ev));
-    RFLU_HIP(hipEventRecord(ev, U));
-    RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
+    if (uend_prev >= 0) {
+        RFLU_TRY(get_event(h, 4 * uend_prev + 3, &ev));
+        RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
+    }
     return RFLU_OK;
 }
 
@@ -373,7 +468,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     Fact<T> f{h, R, ld, m, n, ipiv, pivot};
     bool fat_tail_done = false;
     if (blocksize == 0)  // measured on MI355X (bench.py --blocksize sweep): the knee moves right with the matrix size
-        blocksize = mn < 1024 ? -1 : (mn <= 8192 ? 256 : (mn <= 16384 ? 512 : (mn <= 32768 ? 1024 : 2048)));
+        blocksize = mn < 1024 ? -1 : (mn <= 8192 ? 256 : (mn <= 16384 ? 512 : (mn <= 24576 ? 1024 : 2048)));
     if (blocksize < 0 || blocksize >= mn) {
         h->last_path = RFLU_PATH_HIP_RECURSIVE;
         RFLU_TRY(f.rec(0, mn));
@@ -467,7 +562,7 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
 using namespace rflu;
 
 static Handle* H(rflu_handle_t h) { return reinterpret_cast<Handle*>(h); }
-namespace rflu { int ensure_ustream(Handle* h, int reserve); }
+namespace rflu { int get_ustream(Handle* h, int reserve, hipStream_t* out); }
 
 #define CHECK_HANDLE(h)                        \
     do {                                       \
@@ -548,7 +643,8 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->info_pinned) (void)hipHostFree(h->info_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->ustream) (void)hipStreamDestroy(h->ustream);
+    for (hipStream_t us : h->ustreams)
+        if (us) (void)hipStreamDestroy(us);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -575,8 +671,9 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out)
 {
     CHECK_HANDLE(handle);
     if (hip_stream_out == nullptr) { set_error("null output pointer"); return RFLU_ERR_ARG; }
-    RFLU_TRY(ensure_ustream(H(handle), 32));
-    *hip_stream_out = reinterpret_cast<void*>(H(handle)->ustream);
+    hipStream_t us;
+    RFLU_TRY(get_ustream(H(handle), 32, &us));
+    *hip_stream_out = reinterpret_cast<void*>(us);
     return RFLU_OK;
 }
 

@@ -50,8 +50,7 @@ struct Handle {
     hipStream_t stream = nullptr;
     // second stream for the lookahead driver: the deferred trailing updates run here, restricted by a CU mask to
     // 224 of the 256 CUs so that the cooperative panel kernels of the critical path always find 32 free CUs
-    hipStream_t ustream = nullptr;
-    int ustream_reserve = 0;
+    hipStream_t ustreams[8] = {};     // ustreams[r]: CU mask leaving 32*r CUs to the critical path (r = 1..7)
     std::vector<hipEvent_t> events;   // reusable, timing disabled
     int last_path = RFLU_PATH_NONE;
     int num_cus = 256;

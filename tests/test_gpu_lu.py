@@ -128,6 +128,24 @@ def test_lookahead_shapes(shape, blocksize):
     check_against_oracle(N, rf.LU(Fn.factors, np.arange(1, min(shape) + 1), Fn.info), pivot=False)
 
 
+@pytest.mark.parametrize("shape,blocksize,env", [
+    ((20480, 1024), 128, {"RFLU_SPLIT_SCALE": "0.02"}),     # panels of 33..40 workgroups: 64 CUs reserved, restA/restB split
+    ((20480, 1024), 128, {}),                                # same panels, model-sized split (everything fits on U)
+    ((40000, 640), 128, {}),                                 # panels of 78 workgroups: single-stream block columns
+    ((3000, 3000), 256, {"RFLU_SPLIT_ALL": "1", "RFLU_SPLIT_SCALE": "0.1"}),   # split forced on ordinary panels
+    ((1500, 2600), 256, {"RFLU_SPLIT_ALL": "1", "RFLU_SPLIT_SCALE": "0.1"}),   # ... and on a fat matrix
+])
+def test_lookahead_schedules_tall_panels_and_split(shape, blocksize, env, monkeypatch):
+    # the lookahead driver picks the CU reservation per block column and may hand the tail of an update to the panel
+    # stream (driver.cpp factor_lookahead): same operations on the same columns, so pivots must not move
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    A = rand_matrix(shape[0], shape[1], seed=41)
+    F = rf.lu(A, True, check=False, blocksize=blocksize)
+    assert rf.last_path() == "hip-lookahead"
+    check_against_oracle(A, F)
+
+
 def test_row_major_device_entry():
     A = rand_matrix(700, 700, seed=21)
     d = torch.from_numpy(np.ascontiguousarray(A)).to("cuda:0")

@@ -271,9 +271,17 @@ def main():
             "check": check,
             "kernel_ms": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in kern.items()},
         }
-        print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
+        # that the JSON line is the LAST line of stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -108,6 +108,9 @@ class BlockColumnLU:
         self.meta = [torch.zeros(wmax + 1, dtype=torch.int64, device=device) for _ in range(2)]  # ipiv segment + info
         self.info_dev = torch.zeros((), dtype=torch.int64, device=device)
         self.info = 0
+        # panels taller than this many rows need more than the 32 CUs the update stream leaves free (one 512-row
+        # workgroup per CU): their owner factors them BEFORE its own bulk update instead of next to it
+        self.tall_rows = 32 * 512
 
     # ---- input -------------------------------------------------------------------------------------------------------
     def regenerate(self):
@@ -231,10 +234,6 @@ class BlockColumnLU:
                     wait(P, done[b - 2])          # the buffer was last read by update b-2
                 if self.rank == owner:
                     wait(P, ev_ready)             # this rank's slice has received update b-1
-                    if b >= 1 and (rows + 511) // 512 > 32:
-                        # a panel taller than 32 workgroups does not fit next to the CU-masked update stream (32 CUs are
-                        # kept free): let the bulk update drain first instead of spinning for co-residency
-                        wait(P, done[b - 1])
                     info = ops.panel(self.R, ld, n, j0, lc, w, self.ipiv, self.pivot)
                     panel.copy_(self.R[j0:, lc:lc + w])
                     mt[:w].copy_(self.ipiv[j0:j0 + w])
@@ -263,12 +262,21 @@ class BlockColumnLU:
                     assert self.layout[b + 1][3] == right_start
                     self._update(j0, w, pb, right_start, nxt_slice)
                     ev_ready = record(U)
-                # the bulk of update b is queued BEFORE the (host-blocking) panel call below, so the two overlap on the GPU
+                tall_next = (b + 1 < nb and nxt_slice > 0 and n - self.layout[b + 1][0] > self.tall_rows)
+            if tall_next:
+                # this rank owns a TALL block column b+1: it cannot run next to the update (not enough free CUs), and it is
+                # what every other rank will wait for -- factor and broadcast it first, whole GPU, then catch up on the
+                # bulk of update b while the others are already applying b+1
+                produce(b + 1, ev_ready)
+            with _On(U):
+                if tall_next:
+                    wait(U, recv[b + 1])
+                # (otherwise) the bulk of update b is queued BEFORE the host-blocking panel call, so the two overlap
                 if self.pivot:
                     ops.laswp(self.R, ld, n, 0, left_end, self.ipiv, j0, j0 + w)
                 self._update(j0, w, pb, right_start + nxt_slice, self.n_loc - right_start - nxt_slice)
                 done[b] = record(U)
-            if b + 1 < nb:
+            if b + 1 < nb and not tall_next:
                 produce(b + 1, ev_ready)
         if gpu:
             cur.wait_stream(U)

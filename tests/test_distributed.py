@@ -59,7 +59,7 @@ class NumpyOps:
         _view(R, c0, m, w, ld)[:] = blk
 
 
-def _worker(rank, world, port, n, block, pivot, diag_add, q, sync=False):
+def _worker(rank, world, port, n, block, pivot, diag_add, q, sync=False, tall_rows=None):
     if sync:
         os.environ["RFLU_DIST_SYNC"] = "1"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -70,6 +70,8 @@ def _worker(rank, world, port, n, block, pivot, diag_add, q, sync=False):
 
         job = BlockColumnLU(NumpyOps(), n, torch.float64, rank, world, torch.device("cpu"), block=block, pivot=pivot,
                             seed=12, diag_add=diag_add)
+        if tall_rows is not None:
+            job.tall_rows = tall_rows
         job.regenerate()
         info = job.factor()
         F = job.gather_factors()
@@ -86,15 +88,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n,block,pivot,sync", [(2, 300, 64, True, False), (3, 257, 64, True, False),
-                                                      (2, 200, 128, False, False), (2, 300, 64, True, True)])
-def test_block_column_lu_matches_single_process(world, n, block, pivot, sync):
-    # sync=False: the lookahead schedule (panel b+1 factored and broadcast while update b is still queued);
-    # sync=True : one block column at a time.  Same collectives in the same order on every rank in both.
+@pytest.mark.parametrize("world,n,block,pivot,sync,tall_rows", [
+    (2, 300, 64, True, False, None), (3, 257, 64, True, False, None), (2, 200, 128, False, False, None),
+    (2, 300, 64, True, True, None),
+    (2, 300, 64, True, False, 150),   # block columns with more than 150 rows take the tall-panel order, the rest overlap
+    (3, 321, 64, True, False, 0),     # every block column tall
+])
+def test_block_column_lu_matches_single_process(world, n, block, pivot, sync, tall_rows):
+    # sync=False: the lookahead schedule (panel b+1 factored and broadcast while update b is still queued; a tall panel is
+    # factored by its owner before that owner's bulk update);  sync=True : one block column at a time.
+    # Same collectives in the same order on every rank in all of them.
     diag_add = 0.0 if pivot else 10.0
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, block, pivot, diag_add, q, sync))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, block, pivot, diag_add, q, sync, tall_rows))
              for port in [_free_port()] for r in range(world)]
     for p in procs:
         p.start()

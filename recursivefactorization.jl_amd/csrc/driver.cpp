@@ -207,12 +207,34 @@ struct Fact {
         return RFLU_OK;
     }
 
+    // two full leaves in one cooperative launch (panel.hip: panel_pivot_pair_kernel) + one interchange launch: both
+    // leaves' interchanges on the columns outside the pair, leaf B's on leaf A's columns, both diagonal inverses
+    int leaf_pair(int64_t c0)
+    {
+        const int64_t r0 = c0 + roff;
+        RFLU_TRY(launch_panel_pair<T>(h, R, ld, m, r0, c0, ipiv));
+        const int64_t hi = sw_hi < 0 ? n : sw_hi;
+        return launch_laswp3<T>(h, R, ld, sw_lo, c0 - sw_lo, c0 + 2 * NB, hi - (c0 + 2 * NB), c0, NB, r0 / NB, r0 / NB + 2,
+                                NB, 2, R + r0 * ld + c0, linv_at(r0));
+    }
+
+    bool pair_ok(int64_t c0) const
+    {
+        // opt-in (RFLU_PAIR=1): correct and parity-tested, but at its current inter-leaf cost (~100 us: slot gather 25,
+        // LDS solve 24, LDS-bandwidth-bound Schur update 40) it is 6 % slower than the three launches it replaces
+        const char* e = getenv("RFLU_PAIR");
+        const bool on = e != nullptr && e[0] == '1';
+        const int64_t rows = m - (c0 + roff);
+        return pivot && on && rows >= 2 * NB && (rows + PANEL_THREADS - 1) / PANEL_THREADS <= MAX_PANEL_WGS;
+    }
+
     // reckernel! (src/lu.jl:189-263) on columns [c0, c1), rows [c0+roff, m)
     int rec(int64_t c0, int64_t c1)
     {
         const int64_t w = c1 - c0;
         if (w <= 0) return RFLU_OK;
         if (w <= NB) return leaf(c0, w);
+        if (w == 2 * NB && pair_ok(c0)) return leaf_pair(c0);
         const int64_t leaves = (w + NB - 1) / NB;
         const int64_t n1 = ((leaves + 1) / 2) * NB;
         const int64_t cm = c0 + n1;

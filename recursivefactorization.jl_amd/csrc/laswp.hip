@@ -15,37 +15,49 @@ namespace rflu {
 constexpr int LW_COLS = 64;           // columns per workgroup (one lane per column)
 constexpr int LW_ROWS_PER_THREAD = (2 * NB) / 4;  // 4 waves share the <=128 moves of a chunk
 
-// inv_nb > 0: one extra workgroup (the last) inverts the leaf's 64x64 diagonal block for the fused TRSMs that follow
-// (trsm.hip) -- it rides along with the leaf's interchange launch instead of costing a dependent launch of its own.
+// inv_nb > 0: extra workgroups (the last inv_cnt) invert the leaves' 64x64 diagonal blocks for the fused TRSMs that follow
+// (trsm.hip) -- they ride along with the leaf's interchange launch instead of costing a dependent launch of their own.
+// A third column range [c2, c2+ncolsC) receives only the chunks after the first: for a pair leaf (panel.hip) these are
+// leaf A's own columns, which still need leaf B's interchanges.
 template <typename T>
 __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA,
-                                                    int64_t c1, int64_t ncolsB, const int* __restrict__ pm_cnt,
-                                                    const int* __restrict__ pm_dst, const int* __restrict__ pm_src,
-                                                    int chunk0, int chunk1, int inv_nb, const T* inv_L, T* inv_out)
+                                                    int64_t c1, int64_t ncolsB, int64_t c2, int64_t ncolsC,
+                                                    const int* __restrict__ pm_cnt, const int* __restrict__ pm_dst,
+                                                    const int* __restrict__ pm_src, int chunk0, int chunk1, int inv_nb,
+                                                    int inv_cnt, const T* inv_L, T* inv_out)
 {
     __shared__ T sL[NB * NB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t blocksA = (ncolsA + LW_COLS - 1) / LW_COLS;
     const int64_t blocksB = (ncolsB + LW_COLS - 1) / LW_COLS;
-    if ((int64_t)blockIdx.x >= blocksA + blocksB) {
-        if (inv_nb > 0 && threadIdx.x < 64) diag_inv_block<T>(inv_nb, inv_L, ld, inv_out, sL, lane);
+    const int64_t blocksC = (ncolsC + LW_COLS - 1) / LW_COLS;
+    if ((int64_t)blockIdx.x >= blocksA + blocksB + blocksC) {
+        const int64_t i = (int64_t)blockIdx.x - (blocksA + blocksB + blocksC);
+        if (inv_nb > 0 && i < inv_cnt && threadIdx.x < 64)
+            diag_inv_block<T>(inv_nb, inv_L + i * (NB * ld + NB), ld, inv_out + i * NB * NB, sL, lane);
         return;
     }
-    // two column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB) are covered by one launch (left and right of a panel)
+    // the column ranges are covered by one launch (left and right of a panel, and a pair's first leaf)
     int64_t col;
     bool active;
+    int first = chunk0;
     if ((int64_t)blockIdx.x < blocksA) {
         const int64_t off = (int64_t)blockIdx.x * LW_COLS + lane;
         col = c0 + off;
         active = off < ncolsA;
-    } else {
+    } else if ((int64_t)blockIdx.x < blocksA + blocksB) {
         const int64_t off = ((int64_t)blockIdx.x - blocksA) * LW_COLS + lane;
         col = c1 + off;
         active = off < ncolsB;
+    } else {
+        const int64_t off = ((int64_t)blockIdx.x - blocksA - blocksB) * LW_COLS + lane;
+        col = c2 + off;
+        active = off < ncolsC;
+        first = chunk0 + 1;
     }
     T v[LW_ROWS_PER_THREAD];
-    for (int t = chunk0; t < chunk1; ++t) {
+    for (int t = first; t < chunk1; ++t) {
         // the whole move list of the chunk in four coalesced loads (lane e holds entries e and e+64) ...
         const int cnt = pm_cnt[t];
         const int s0 = pm_src[(size_t)t * 2 * NB + lane], s1 = pm_src[(size_t)t * 2 * NB + NB + lane];
@@ -68,24 +80,38 @@ __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t l
     }
 }
 
-// Apply chunks [chunk0, chunk1) to the column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB); optionally invert the
-// inv_nb x inv_nb unit lower block at inv_L (leading dimension ld) into inv_out in the same launch.
+// Apply chunks [chunk0, chunk1) to the column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB), and chunks [chunk0+1, chunk1) to
+// [c2, c2+ncolsC); optionally invert inv_cnt consecutive inv_nb x inv_nb unit lower diagonal blocks starting at inv_L
+// (leading dimension ld) into inv_out in the same launch.
+template <typename T>
+int launch_laswp3(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t c2,
+                  int64_t ncolsC, int64_t chunk0, int64_t chunk1, int64_t inv_nb, int64_t inv_cnt, const T* inv_L,
+                  T* inv_out)
+{
+    if (ncolsA < 0) ncolsA = 0;
+    if (ncolsB < 0) ncolsB = 0;
+    if (ncolsC < 0 || chunk1 - chunk0 < 2) ncolsC = 0;
+    const bool swaps = chunk1 > chunk0 && ncolsA + ncolsB + ncolsC > 0;
+    if (inv_nb <= 0) inv_cnt = 0;
+    if (!swaps && inv_cnt <= 0) return RFLU_OK;
+    if (!swaps) { ncolsA = ncolsB = ncolsC = 0; }
+    const int64_t blocks = (ncolsA + LW_COLS - 1) / LW_COLS + (ncolsB + LW_COLS - 1) / LW_COLS +
+                           (ncolsC + LW_COLS - 1) / LW_COLS + inv_cnt;
+    ProfScope ps(h, RFLU_K_LASWP, 4.0 * sizeof(T) * (double)NB *
+                                      ((double)(ncolsA + ncolsB) * (double)(chunk1 - chunk0) +
+                                       (double)ncolsC * (double)(chunk1 - chunk0 - 1)));
+    hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, h->stream, R, ld, c0, ncolsA, c1, ncolsB, c2,
+                       ncolsC, h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk0, (int)chunk1, (int)inv_nb, (int)inv_cnt, inv_L,
+                       inv_out);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
 template <typename T>
 int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t chunk0,
                   int64_t chunk1, int64_t inv_nb, const T* inv_L, T* inv_out)
 {
-    if (ncolsA < 0) ncolsA = 0;
-    if (ncolsB < 0) ncolsB = 0;
-    const bool swaps = chunk1 > chunk0 && ncolsA + ncolsB > 0;
-    if (!swaps && inv_nb <= 0) return RFLU_OK;
-    if (!swaps) { ncolsA = ncolsB = 0; }
-    const int64_t blocks = (ncolsA + LW_COLS - 1) / LW_COLS + (ncolsB + LW_COLS - 1) / LW_COLS + (inv_nb > 0 ? 1 : 0);
-    ProfScope ps(h, RFLU_K_LASWP,
-                 4.0 * sizeof(T) * (double)(ncolsA + ncolsB) * (double)NB * (double)(chunk1 - chunk0));
-    hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, h->stream, R, ld, c0, ncolsA, c1, ncolsB,
-                       h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk0, (int)chunk1, (int)inv_nb, inv_L, inv_out);
-    RFLU_HIP(hipGetLastError());
-    return RFLU_OK;
+    return launch_laswp3<T>(h, R, ld, c0, ncolsA, c1, ncolsB, 0, 0, chunk0, chunk1, inv_nb, 1, inv_L, inv_out);
 }
 
 template <typename T>
@@ -96,6 +122,8 @@ int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t
 
 template int launch_laswp<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t);
 template int launch_laswp<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t);
+template int launch_laswp3<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, double*);
+template int launch_laswp3<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const float*, float*);
 template int launch_laswp2<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, double*);
 template int launch_laswp2<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const float*, float*);
 

@@ -50,10 +50,21 @@ constexpr unsigned PS_ROW_BYTES = NB * PS_VAL_BYTES;        // per workgroup can
 constexpr unsigned PS_HDR_REGION = MAX_PANEL_WGS * PS_HDR_BYTES;
 constexpr unsigned PS_BUF_BYTES = PS_HDR_REGION + MAX_PANEL_WGS * PS_ROW_BYTES;  // one parity buffer
 constexpr size_t PS_TOTAL_WORDS = 2 * (size_t)PS_BUF_BYTES / 8;
+constexpr size_t PS_TRACE_WORDS = 8 * NB + 16;              // RFLU_PANEL_TRACE stamps live right after the records
+// pair leaf (two leaves in one launch): slot k = {L11 row k | raw leaf-B row of pivot k}, 2*NB granules each
+constexpr unsigned PX_SLOT_BYTES = 2 * NB * PS_VAL_BYTES;
+constexpr unsigned PX_BYTES = NB * PX_SLOT_BYTES;
+constexpr size_t PX_OFFSET_WORDS = PS_TOTAL_WORDS + PS_TRACE_WORDS;
+constexpr int PX_UL = NB + 1;                                          // LDS row stride of U12 (bank spread)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t scratch_rsrc(u64* scratch)
 {
     return __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 2 * PS_BUF_BYTES, 0x00020000);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pair_rsrc(u64* scratch)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(scratch + PX_OFFSET_WORDS, 0, PX_BYTES, 0x00020000);
 }
 
 template <typename T>
@@ -67,6 +78,14 @@ struct Gran<double> {
     }
     static __device__ __forceinline__ bool load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, double& v) {
         const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
+        v = __longlong_as_double((long long)(((u64)x[0] << 32) | (u64)x[2]));
+        return x[1] == tag && x[3] == tag;
+    }
+    typedef u4v raw_t;
+    static __device__ __forceinline__ raw_t load_raw(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
+    }
+    static __device__ __forceinline__ bool unpack(raw_t x, unsigned tag, double& v) {
         v = __longlong_as_double((long long)(((u64)x[0] << 32) | (u64)x[2]));
         return x[1] == tag && x[3] == tag;
     }
@@ -97,6 +116,14 @@ struct Gran<float> {
     }
     static __device__ __forceinline__ bool load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, float& v) {
         const u2v x = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, AUX_SC1);
+        v = __uint_as_float(x[0]);
+        return x[1] == tag;
+    }
+    typedef u2v raw_t;
+    static __device__ __forceinline__ raw_t load_raw(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, AUX_SC1);
+    }
+    static __device__ __forceinline__ bool unpack(raw_t x, unsigned tag, float& v) {
         v = __uint_as_float(x[0]);
         return x[1] == tag;
     }
@@ -321,13 +348,84 @@ __device__ __forceinline__ void store_row_direct(T* __restrict__ R, int64_t ld, 
     }
 }
 
+// ---- the same bookkeeping, incrementally and in registers -----------------------------------------------------------
+// perm_build_wave costs ~64 dependent LDS round trips (15-20 us) when run after the last pivot step.  The cooperative kernels
+// instead let ONE wave (the last wave of workgroup 0) carry the slot contents across the pivot steps in registers: lane s
+// holds content[s] and content[NB+s], lane x holds the row of extra slot x; a step is a few readlane / select operations.
+struct PermState {
+    int c_lo;    // content[lane]
+    int c_hi;    // content[NB + lane]
+    int r_hi;    // rows[NB + lane] (row index of extra slot `lane`, -1 = unused)
+    int nextra;  // number of extra slots in use (wave-uniform)
+};
+
+__device__ __forceinline__ PermState perm_state_init(int lane)
+{
+    PermState ps;
+    ps.c_lo = lane;
+    ps.c_hi = NB + lane;
+    ps.r_hi = -1;
+    ps.nextra = 0;
+    return ps;
+}
+
+// interchange  position base+i <-> row p  (p wave-uniform)
+__device__ __forceinline__ void perm_state_step(PermState& ps, int base, int i, int p, int lane)
+{
+    int sp;
+    if (p < base + NB) {
+        sp = p - base;
+    } else {
+        const u64 mask = __ballot(lane < ps.nextra && ps.r_hi == p);
+        if (mask) {
+            sp = NB + (__ffsll((long long)mask) - 1);
+        } else {
+            sp = NB + ps.nextra;
+            if (lane == ps.nextra) ps.r_hi = p;
+            ++ps.nextra;
+        }
+    }
+    sp = __builtin_amdgcn_readfirstlane(sp);
+    if (sp != i) {
+        const int ci = __builtin_amdgcn_readlane(ps.c_lo, i);
+        const int cs = (sp < NB) ? __builtin_amdgcn_readlane(ps.c_lo, sp & (NB - 1))
+                                 : __builtin_amdgcn_readlane(ps.c_hi, sp & (NB - 1));
+        if (lane == i) ps.c_lo = cs;
+        if (sp < NB) { if (lane == sp) ps.c_lo = ci; }
+        else { if (lane == sp - NB) ps.c_hi = ci; }
+    }
+}
+
+// compact the slots whose content changed into the move list of the chunk (rows_tmp: NB ints of LDS)
+__device__ __forceinline__ void perm_state_finish(const PermState& ps, int base, int lane, int* rows_tmp, int* out_cnt,
+                                                  int* out_dst, int* out_src)
+{
+    rows_tmp[lane] = ps.r_hi;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    int total = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int s = half * NB + lane;
+        const int c = half ? ps.c_hi : ps.c_lo;
+        const bool moved = (half == 0 || lane < ps.nextra) && (c != s);
+        const u64 mask = __ballot(moved);
+        if (moved) {
+            const int off = total + __popcll(mask & ((1ull << lane) - 1ull));
+            out_dst[off] = half ? ps.r_hi : base + lane;
+            out_src[off] = (c < NB) ? base + c : rows_tmp[c - NB];
+        }
+        total += __popcll(mask);
+    }
+    if (lane == 0) *out_cnt = total;
+}
+
 // =====================================================================================================================
 // Pivoted leaf panel
 // =====================================================================================================================
 // ---- all LDS state of the pivoted kernel in ONE object (passed around as a single LDS pointer) ----------------------
 template <typename T>
 struct PivotLds {
-    T tile[64 * TILE_LD];   // row <-> register staging
     T prow[NB];             // pivot row of this step (columns k..NB-1 valid)
     T wval[PANEL_WAVES];
     unsigned wpos[PANEL_WAVES];
@@ -472,6 +570,7 @@ struct MidOut {
     T scale;         // 1/pivot (or 1 when the pivot is exactly zero)
     unsigned pos;    // this thread's row position after the interchange
     unsigned flags;  // bit0: apply the update to this row, bit1: row still active, bit2: give up (timeout)
+    PermState perm;  // interchange bookkeeping (meaningful in the last wave of workgroup 0 only)
 };
 
 // step_b: wave 0 polls the G headers (both 16-byte halves of a header in flight together), all workgroups arrive at the
@@ -479,7 +578,7 @@ struct MidOut {
 //         bookkeeping for this thread's row.
 template <typename T>
 __device__ __noinline__ MidOut<T> step_b(PivotLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch,
-                                         int G, int k, int r0, int g, int tid, unsigned pos, bool act)
+                                         int G, int k, int r0, int g, int tid, unsigned pos, bool act, PermState perm)
 {
     const int lane = tid & 63, wave = tid >> 6;
     if (G > 1 && wave == 0) {
@@ -548,14 +647,16 @@ __device__ __noinline__ MidOut<T> step_b(PivotLds<T>* sh, u64* scratch, int64_t*
     o.scale = T(1);
     o.pos = pos;
     o.flags = (act ? 2u : 0u) | (sh->dead ? 4u : 0u);
+    o.perm = perm;
     const unsigned win_pos = sh->win;
     if (win_pos == POS_NONE) return o;
+    if (g == 0 && wave == PANEL_WAVES - 1)
+        perm_state_step(o.perm, r0, k, __builtin_amdgcn_readfirstlane((int)win_pos), lane);
     const T piv = sh->prow[k];
     const bool has = (piv != T(0));
     const unsigned kpos = (unsigned)(r0 + k);
     if (g == 0 && tid == 0) {
         ipiv[r0 + k] = (int64_t)win_pos + 1;
-        sh->piv[k] = (int)win_pos;
         if (!has && info[0] == 0) info[0] = (int64_t)r0 + k + 1;
     }
     o.scale = sh->scale;
@@ -574,7 +675,7 @@ __device__ __noinline__ MidOut<T> step_b(PivotLds<T>* sh, u64* scratch, int64_t*
 // One pivot step, K a compile-time constant so that every register-array index below is static.
 template <typename T, int K>
 __device__ __forceinline__ void pivot_step(const PanelArgs<T>& p, PivotLds<T>* sh, T (&a)[NB], unsigned& pos, bool& act,
-                                           bool& dead, int g, int tid)
+                                           bool& dead, PermState& perm, int g, int tid)
 {
     if (K >= p.w || dead) return;
     RFLU_STAMP(p.scratch, K, 0, g, tid);
@@ -596,7 +697,8 @@ __device__ __forceinline__ void pivot_step(const PanelArgs<T>& p, PivotLds<T>* s
             for (int j = K; j < NB; ++j) Gran<T>::store(rs, roff + j * PS_VAL_BYTES, tag, a[j]);
         }
     }
-    const MidOut<T> o = step_b<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.r0, g, tid, pos, act);
+    const MidOut<T> o = step_b<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.r0, g, tid, pos, act, perm);
+    perm = o.perm;
     RFLU_STAMP(p.scratch, K, 5, g, tid);
     pos = o.pos;
     act = (o.flags & 2u) != 0;
@@ -613,11 +715,11 @@ __device__ __forceinline__ void pivot_step(const PanelArgs<T>& p, PivotLds<T>* s
 template <typename T, int K0, int K1>
 struct PivotSteps {
     static __device__ __forceinline__ void run(const PanelArgs<T>& p, PivotLds<T>* sh, T (&a)[NB], unsigned& pos,
-                                               bool& act, bool& dead, int g, int tid)
+                                               bool& act, bool& dead, PermState& perm, int g, int tid)
     {
         if constexpr (K0 < K1) {
-            pivot_step<T, K0>(p, sh, a, pos, act, dead, g, tid);
-            PivotSteps<T, K0 + 1, K1>::run(p, sh, a, pos, act, dead, g, tid);
+            pivot_step<T, K0>(p, sh, a, pos, act, dead, perm, g, tid);
+            PivotSteps<T, K0 + 1, K1>::run(p, sh, a, pos, act, dead, perm, g, tid);
         }
     }
 };
@@ -645,7 +747,8 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_kernel(PanelArgs<T>
     RFLU_STAMP(p.scratch, NB, 1, g, tid);
 
     bool dead = false;  // set (workgroup-uniformly) after a timeout: skip the remaining steps quickly
-    PivotSteps<T, 0, NB>::run(p, sh, a[0], pos, act, dead, g, tid);
+    PermState perm = perm_state_init(lane);
+    PivotSteps<T, 0, NB>::run(p, sh, a[0], pos, act, dead, perm, g, tid);
 
     RFLU_STAMP(p.scratch, NB, 2, g, tid);
     store_row_direct<T>(p.R, p.ld, pos, p.c0, w, a[0]);
@@ -653,10 +756,178 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_kernel(PanelArgs<T>
     RFLU_STAMP(p.scratch, NB, 3, g, tid);
 
     if (g == 0 && wave == PANEL_WAVES - 1) {
-        __threadfence_block();
         const int chunk = p.r0 / NB;
-        perm_build_wave(sh->piv, p.r0, w, lane, sh->rows, sh->content, p.pm_cnt + chunk,
-                        p.pm_dst + (size_t)chunk * 2 * NB, p.pm_src + (size_t)chunk * 2 * NB);
+        perm_state_finish(perm, p.r0, lane, sh->rows, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
+                          p.pm_src + (size_t)chunk * 2 * NB);
+    }
+}
+
+// =====================================================================================================================
+// Pair leaf: two adjacent 64-column leaves (columns [c0, c0+64) and [c0+64, c0+128)) in ONE cooperative launch.
+// Between the two leaves the recursion would run  interchanges -> 64x64 unit-lower solve -> K=64 Schur update
+// (src/lu.jl:233-240 at the lowest level) as three dependent launches; here every thread does that for its own row:
+//   * leaf A's interchanges on leaf B's columns are implicit: a thread keeps its row (tracking its position) and reads the
+//     row's leaf-B part from where it physically still lies;
+//   * the 64 pivot-row owners publish {their L11 row, their raw leaf-B row}; every workgroup gathers the 64 slots and
+//     solves U12 = L11^-1 * B_piv redundantly in LDS (forward substitution, 64 steps);
+//   * every other row subtracts l_i * U12 from its leaf-B part in registers (l_i re-read from the row it just stored).
+// Leaf B then runs on the same registers.  Its interchanges still have to reach leaf A's columns: the caller's laswp
+// launch does that (chunk B on columns [c0, c0+64)).
+// =====================================================================================================================
+template <typename T>
+struct PairLds {
+    T ltri[NB * (NB - 1) / 2];   // strictly lower part of L11, packed by rows: (k,t) at k(k-1)/2 + t
+    T u12[NB * PX_UL];           // raw leaf-B rows of the 64 pivots, then U12 (row stride PX_UL)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_pair_kernel(PanelArgs<T> p)
+{
+    __shared__ PivotLds<T> s_lds;
+    __shared__ PairLds<T> s_pair;
+    PivotLds<T>* const sh = &s_lds;
+    PairLds<T>* const px = &s_pair;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int row_base = p.r0 + g * PANEL_THREADS;
+    const int row = row_base + tid;
+    const bool valid = row < p.m;
+    bool act = valid;
+    unsigned pos = valid ? (unsigned)row : POS_NONE;
+    if (tid == 0) sh->dead = 0;
+    T a[NB];
+    load_row_direct<T>(p.R, p.ld, row, valid, p.c0, NB, a);
+    __syncthreads();
+
+    PanelArgs<T> q = p;
+    q.w = NB;
+    bool dead = false;
+    PermState perm = perm_state_init(lane);
+    bool pivot_a = false;   // this thread's row became one of leaf A's pivots (position r0 + ka)
+    int ka = 0;
+#pragma nounroll
+    for (int phase = 0; phase < 2; ++phase) {
+        PivotSteps<T, 0, NB>::run(q, sh, a, pos, act, dead, perm, g, tid);
+        if (phase == 1 || dead) break;
+
+        // ---------------- between the leaves ----------------
+        RFLU_STAMP(p.scratch, NB, 4, g, tid);
+        const __amdgpu_buffer_rsrc_t rx = pair_rsrc(p.scratch);
+        const unsigned tagx = p.epoch + 2u * NB;
+        pivot_a = valid && !act;
+        ka = pivot_a ? (int)pos - p.r0 : 0;
+        if (pivot_a) {  // L11 row (columns < ka are L, the rest is U11 and ignored by the readers)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) Gran<T>::store(rx, (unsigned)ka * PX_SLOT_BYTES + j * PS_VAL_BYTES, tagx, a[j]);
+        }
+        store_row_direct<T>(p.R, p.ld, pos, p.c0, NB, a);               // leaf A's part goes to the row's position
+        if (g == 0 && wave == PANEL_WAVES - 1) {                        // chunk A's move list; fresh state for leaf B
+            const int chunk = p.r0 / NB;
+            perm_state_finish(perm, p.r0, lane, sh->rows, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
+                              p.pm_src + (size_t)chunk * 2 * NB);
+            perm = perm_state_init(lane);
+        }
+        load_row_direct<T>(p.R, p.ld, row, valid, p.c0 + NB, NB, a);    // leaf B's part: still at the row's ORIGINAL place
+        if (pivot_a) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                Gran<T>::store(rx, (unsigned)ka * PX_SLOT_BYTES + (NB + j) * PS_VAL_BYTES, tagx, a[j]);
+        }
+        RFLU_STAMP(p.scratch, NB, 5, g, tid);
+        // gather the 64 slots: 2*NB*NB granules, 16 per thread, all loads in flight before the first tag is checked
+        {
+            constexpr int PER = (2 * NB * NB) / PANEL_THREADS, BATCH = 8;
+            bool timed_out = false;
+#pragma unroll
+            for (int i0 = 0; i0 < PER; i0 += BATCH) {
+                typename Gran<T>::raw_t raw[BATCH];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int idx = (i0 + i) * PANEL_THREADS + tid;
+                    raw[i] = Gran<T>::load_raw(rx, (unsigned)(idx >> 7) * PX_SLOT_BYTES + (unsigned)(idx & (2 * NB - 1)) * PS_VAL_BYTES);
+                }
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int idx = (i0 + i) * PANEL_THREADS + tid;
+                    const int slot = idx >> 7, j = idx & (2 * NB - 1);
+                    T v = T(0);
+                    if (!Gran<T>::unpack(raw[i], tagx, v)) {
+                        int spins = 0;
+                        for (;;) {
+                            asm volatile("" ::: "memory");
+                            if (Gran<T>::load(rx, (unsigned)slot * PX_SLOT_BYTES + (unsigned)j * PS_VAL_BYTES, tagx, v)) break;
+                            if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+                            if (spins > 4) __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    if (j >= NB) px->u12[slot * PX_UL + (j - NB)] = v;
+                    else if (j < slot) px->ltri[slot * (slot - 1) / 2 + j] = v;
+                }
+            }
+            if (timed_out) {
+                __hip_atomic_store((u64*)(p.info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh->dead = 1;
+            }
+        }
+        __syncthreads();
+        if (sh->dead) { dead = true; break; }
+        RFLU_STAMP(p.scratch, NB, 6, g, tid);
+        // U12 = L11^-1 * B_piv in LDS, right-looking: row t is final after step t-1; rows k > t (one per wave and
+        // round) subtract L11[k][t] * U12[t].  Lane = column.  (A per-wave variant without workgroup barriers -- every
+        // wave solving 8 columns on its own -- measured slower: 31 vs 24 us.)
+#pragma nounroll
+        for (int t = 0; t < NB - 1; ++t) {
+            const T ut = px->u12[t * PX_UL + lane];
+            for (int k = t + 1 + wave; k < NB; k += PANEL_WAVES)
+                px->u12[k * PX_UL + lane] -= px->ltri[k * (k - 1) / 2 + t] * ut;
+            __syncthreads();
+        }
+        RFLU_STAMP(p.scratch, NB, 7, g, tid);
+        // Schur update of this row's leaf-B part: b -= l * U12, l = the leaf-A part stored above.  U12 rows are read
+        // from LDS (same address in every lane) 16 values at a time; the fences bound how far hipcc hoists those reads.
+        // This is LDS-bandwidth bound (64 x 8 B returned per multiply-add: ~40 us per pair).  Feeding the values through
+        // the scalar unit instead (U12 parked in global scratch, s_load -> SGPR operands) measured 55-120 us: hipcc waits
+        // for every 64-byte scalar load before its 8 multiply-adds.  The fix is an MFMA formulation.
+        if (act) {
+            constexpr int LC = 8, UG = 16;
+            const T* lrow = p.R + (int64_t)pos * p.ld + p.c0;
+#pragma nounroll
+            for (int c = 0; c < NB / LC; ++c) {
+                T l[LC];
+#pragma unroll
+                for (int e = 0; e < LC; ++e) l[e] = lrow[c * LC + e];
+#pragma unroll
+                for (int e = 0; e < LC; ++e) {
+                    const T* urow = &px->u12[(c * LC + e) * PX_UL];
+#pragma unroll
+                    for (int j0 = 0; j0 < NB; j0 += UG) {
+                        T uv[UG];
+#pragma unroll
+                        for (int j = 0; j < UG; ++j) uv[j] = urow[j0 + j];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < UG; ++j) a[j0 + j] -= l[e] * uv[j];
+                    }
+                }
+            }
+        }
+        RFLU_STAMP(p.scratch, NB, 8, g, tid);
+        q.r0 += NB;
+        q.c0 += NB;
+        q.epoch += NB;
+    }
+
+    if (pivot_a && !dead) {  // leaf A's pivot rows: their leaf-B part is a row of U12
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[j] = px->u12[ka * PX_UL + j];
+    }
+    store_row_direct<T>(p.R, p.ld, pos, p.c0 + NB, NB, a);
+    __syncthreads();
+    if (g == 0 && wave == PANEL_WAVES - 1) {
+        const int chunk = p.r0 / NB + 1;
+        perm_state_finish(perm, p.r0 + NB, lane, sh->rows, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
+                          p.pm_src + (size_t)chunk * 2 * NB);
     }
 }
 
@@ -795,10 +1066,38 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
     return RFLU_OK;
 }
 
+// Two full leaves [c0, c0+64) and [c0+64, c0+128), pivoted, in one launch (see panel_pivot_pair_kernel).
+template <typename T>
+int launch_panel_pair(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0, int64_t* ipiv)
+{
+    const int64_t rows = m - r0;
+    if (r0 % NB != 0 || rows < 2 * NB || (rows + PANEL_THREADS - 1) / PANEL_THREADS > MAX_PANEL_WGS) {
+        set_error("launch_panel_pair: unsupported geometry m=%lld r0=%lld", (long long)m, (long long)r0);
+        return RFLU_ERR_ARG;
+    }
+    if (h->epoch > 0xfffff000u) {  // tag wrap: wipe the records and restart the epoch counter
+        RFLU_HIP(hipMemsetAsync(h->pscratch, 0, h->pscratch_bytes, h->stream));
+        h->epoch = 1;
+    }
+    PanelArgs<T> p;
+    p.R = R; p.ld = ld; p.m = (int)m; p.r0 = (int)r0; p.c0 = (int)c0; p.w = 2 * NB;
+    p.ipiv = ipiv; p.info = h->info_dev; p.scratch = h->pscratch;
+    p.G = (int)((rows + PANEL_THREADS - 1) / PANEL_THREADS);
+    p.pm_cnt = h->pm_cnt; p.pm_dst = h->pm_dst; p.pm_src = h->pm_src;
+    p.epoch = h->epoch;
+    h->epoch += 2u * NB + 1u;   // 128 step tags + one for the slot exchange
+    ProfScope ps(h, RFLU_K_PANEL, (double)rows * 4.0 * NB * NB);
+    hipLaunchKernelGGL((panel_pivot_pair_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+template int launch_panel_pair<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t*);
+template int launch_panel_pair<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t*);
+
 template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 template int launch_panel<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 
-size_t panel_scratch_bytes() { return (PS_TOTAL_WORDS + 8 * NB + 16) * sizeof(u64); }  // + room for RFLU_PANEL_TRACE stamps
+size_t panel_scratch_bytes() { return (PX_OFFSET_WORDS + PX_BYTES / 8) * sizeof(u64); }  // records | trace stamps | pair slots
 size_t panel_trace_offset_bytes() { return PS_TOTAL_WORDS * sizeof(u64); }
 
 }  // namespace rflu

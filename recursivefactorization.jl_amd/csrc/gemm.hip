@@ -208,6 +208,106 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
     }
 }
 
+// ---- latency-bound updates of the panel recursion: K a small multiple of 64, few tiles -------------------------------------
+// The recursion inside a block column issues C -= A*B with K = 64, 128, (256) and N = K on the critical path.  With the
+// kernel above such a launch is a chain of K/16 dependent {global load -> LDS -> barrier -> MFMA} rounds (18 / 28 us
+// standalone at M = 16384; 2-3x that next to the bulk update that owns most CUs).  Here a workgroup (4 waves) takes a
+// 64x64 tile and issues EVERY load of a 64-wide K chunk at once:
+//   * A never touches LDS: with the K index permuted as k = 16*kk + s (kk = lane>>4, s = MFMA step), the A operand of
+//     lane (i, kk) for the 16 steps of a chunk is 16 CONTIGUOUS elements of row i -- four 16-byte loads;
+//   * B (64 x 64 per chunk) goes through LDS once (odd row stride: conflict-free for the permuted rows);
+//   * the C tile is read into registers up front, so one memory round trip covers everything the tile needs.
+// The sum over k is the same set of products; only the order inside the MFMA accumulation differs.
+constexpr int S_BM = 64, S_BN = 64, S_KC = 64;
+constexpr int S_SB = S_BN + 1;
+
+template <typename T, int NCHUNK>
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs<T> g)
+{
+    typedef typename Mfma<T>::acc_t acc_t;
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    __shared__ T Bs[NCHUNK][S_KC * S_SB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile_m = blockIdx.x % g.tiles_m, tile_n = blockIdx.x / g.tiles_m;
+    const int m0 = tile_m * S_BM, n0 = tile_n * S_BN;
+    const int li = lane & 15, kk = lane >> 4;
+    const int arow = m0 + wave * 16 + li;
+    const bool arow_ok = arow < g.M;
+    const T* Ap = g.A + (int64_t)(arow_ok ? arow : 0) * g.lda + kk * 16;
+
+    // every load of the tile is issued before the first use: A operands (registers), B chunks, the C tile
+    T ra[NCHUNK][16];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+#pragma unroll
+        for (int v = 0; v < 16 / VW; ++v) {
+            const vec_t x = *reinterpret_cast<const vec_t*>(Ap + c * S_KC + v * VW);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) ra[c][v * VW + e] = arow_ok ? x[e] : T(0);
+        }
+    }
+    // B chunk: 64 rows x 64 columns, 16 elements per thread (row tid>>2, columns (tid&3)*16 ..)
+    const int brow = tid >> 2, bcol = (tid & 3) * 16;
+    T rb[NCHUNK][16];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const T* Bp = g.B + (int64_t)(c * S_KC + brow) * g.ldb + n0 + bcol;
+        if (n0 + S_BN <= g.N) {
+#pragma unroll
+            for (int v = 0; v < 16 / VW; ++v) {
+                const vec_t x = *reinterpret_cast<const vec_t*>(Bp + v * VW);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) rb[c][v * VW + e] = x[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rb[c][e] = (n0 + bcol + e < g.N) ? Bp[e] : T(0);
+        }
+    }
+    // C tile: for a fixed (j, r) sixteen lanes cover 16 consecutive columns of one row
+    T cin[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wave * 16 + Mfma<T>::crow(lane, r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + j * 16 + li;
+            cin[j][r] = (row < g.M && col < g.N) ? g.C[(int64_t)row * g.ldc + col] : T(0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Bs[c][brow * S_SB + bcol + e] = rb[c][e];
+    }
+    __syncthreads();
+    acc_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const T* brow_p = &Bs[c][(kk * 16 + st) * S_SB + li];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = Mfma<T>::run(ra[c][st], brow_p[j * 16], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wave * 16 + Mfma<T>::crow(lane, r);
+        if (row < g.M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + j * 16 + li;
+                if (col < g.N) g.C[(int64_t)row * g.ldc + col] = cin[j][r] - acc[j][r];
+            }
+        }
+    }
+}
+
 template <typename T>
 int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C,
                 int64_t ldc)
@@ -221,6 +321,20 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
     constexpr int VW = 16 / (int)sizeof(T);
     g.vec_ok = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0) && (lda % VW == 0) &&
                (ldb % VW == 0);
+    {   // small K, few tiles: the latency-optimised kernel (measured crossover, scripts/microbench_gemm_small.py)
+        static const int skinny_max_k = [] { const char* e = getenv("RFLU_SKINNY_MAXK"); return e ? atoi(e) : 128; }();
+        if (g.vec_ok && (K == S_KC || K == 2 * S_KC) && K <= skinny_max_k && N <= 2 * K) {
+            g.tiles_m = (int)((M + S_BM - 1) / S_BM);
+            g.tiles_n = (int)((N + S_BN - 1) / S_BN);
+            ProfScope ps(h, RFLU_K_GEMM, 2.0 * (double)M * (double)N * (double)K,
+                         sizeof(T) * ((double)M * K + (double)K * N + 2.0 * (double)M * N));
+            const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+            if (K == S_KC) hipLaunchKernelGGL((gemm_skinny_kernel<T, 1>), grid, dim3(256), 0, h->stream, g);
+            else           hipLaunchKernelGGL((gemm_skinny_kernel<T, 2>), grid, dim3(256), 0, h->stream, g);
+            RFLU_HIP(hipGetLastError());
+            return RFLU_OK;
+        }
+    }
     const size_t lds = 2 * (size_t)G_STAGE * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {

@@ -14,7 +14,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(128, 128, 16), (256, 384, 64), (130, 70, 33), (1, 1, 1), (64, 300, 200),
-                                   (513, 257, 129), (1024, 1024, 512)])
+                                   (513, 257, 129), (1024, 1024, 512),
+                                   # K = 64 / 128 with N <= 2K: the latency-optimised kernel of the panel recursion
+                                   (64, 64, 64), (200, 64, 64), (1000, 100, 64), (513, 128, 128), (70, 256, 128),
+                                   (3000, 70, 128), (2048, 128, 64)])
 def test_gemm_sub(dtype, shape):
     # schur_complement! (src/lu.jl:265-284): C <- C - A*B ; asymmetric operands catch transposed fragments
     M, N, K = shape

@@ -570,15 +570,14 @@ struct MidOut {
     T scale;         // 1/pivot (or 1 when the pivot is exactly zero)
     unsigned pos;    // this thread's row position after the interchange
     unsigned flags;  // bit0: apply the update to this row, bit1: row still active, bit2: give up (timeout)
-    PermState perm;  // interchange bookkeeping (meaningful in the last wave of workgroup 0 only)
-};
+};                   // 16 bytes: returned in registers (a larger struct goes through scratch memory on every step)
 
 // step_b: wave 0 polls the G headers (both 16-byte halves of a header in flight together), all workgroups arrive at the
 //         same winner (max |a_pk|, lowest position), fetch the winner's row into LDS; barrier; position / ipiv / info
 //         bookkeeping for this thread's row.
 template <typename T>
 __device__ __noinline__ MidOut<T> step_b(PivotLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch,
-                                         int G, int k, int r0, int g, int tid, unsigned pos, bool act, PermState perm)
+                                         int G, int k, int r0, int g, int tid, unsigned pos, bool act)
 {
     const int lane = tid & 63, wave = tid >> 6;
     if (G > 1 && wave == 0) {
@@ -647,11 +646,8 @@ __device__ __noinline__ MidOut<T> step_b(PivotLds<T>* sh, u64* scratch, int64_t*
     o.scale = T(1);
     o.pos = pos;
     o.flags = (act ? 2u : 0u) | (sh->dead ? 4u : 0u);
-    o.perm = perm;
     const unsigned win_pos = sh->win;
     if (win_pos == POS_NONE) return o;
-    if (g == 0 && wave == PANEL_WAVES - 1)
-        perm_state_step(o.perm, r0, k, __builtin_amdgcn_readfirstlane((int)win_pos), lane);
     const T piv = sh->prow[k];
     const bool has = (piv != T(0));
     const unsigned kpos = (unsigned)(r0 + k);
@@ -697,8 +693,11 @@ __device__ __forceinline__ void pivot_step(const PanelArgs<T>& p, PivotLds<T>* s
             for (int j = K; j < NB; ++j) Gran<T>::store(rs, roff + j * PS_VAL_BYTES, tag, a[j]);
         }
     }
-    const MidOut<T> o = step_b<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.r0, g, tid, pos, act, perm);
-    perm = o.perm;
+    const MidOut<T> o = step_b<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.r0, g, tid, pos, act);
+    if (g == 0 && (tid >> 6) == PANEL_WAVES - 1) {  // interchange bookkeeping: one wave, registers only (sh->win is stable
+        const unsigned wp = sh->win;                // until the next step's barrier)
+        if (wp != POS_NONE) perm_state_step(perm, p.r0, K, __builtin_amdgcn_readfirstlane((int)wp), tid & 63);
+    }
     RFLU_STAMP(p.scratch, K, 5, g, tid);
     pos = o.pos;
     act = (o.flags & 2u) != 0;

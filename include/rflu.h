@@ -51,7 +51,8 @@ enum rflu_kclass {
     RFLU_K_PANEL = 3,     /* _generic_lufact!   (src/lu.jl:290-338) cooperative leaf panel */
     RFLU_K_TRANSPOSE = 4, /* column-major <-> internal row-major layout change at the boundary */
     RFLU_K_MISC = 5,      /* pivot bookkeeping, fills */
-    RFLU_K_COUNT = 6
+    RFLU_K_GEMM_SMALL = 6, /* the same update for K = 64 / 128 inside the panel recursion (latency-bound kernel) */
+    RFLU_K_COUNT = 7
 };
 
 /* ---- lifetime ---- */

@@ -326,7 +326,7 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
         if (g.vec_ok && (K == S_KC || K == 2 * S_KC) && K <= skinny_max_k && N <= 2 * K) {
             g.tiles_m = (int)((M + S_BM - 1) / S_BM);
             g.tiles_n = (int)((N + S_BN - 1) / S_BN);
-            ProfScope ps(h, RFLU_K_GEMM, 2.0 * (double)M * (double)N * (double)K,
+            ProfScope ps(h, RFLU_K_GEMM_SMALL, 2.0 * (double)M * (double)N * (double)K,
                          sizeof(T) * ((double)M * K + (double)K * N + 2.0 * (double)M * N));
             const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
             if (K == S_KC) hipLaunchKernelGGL((gemm_skinny_kernel<T, 1>), grid, dim3(256), 0, h->stream, g);

@@ -9,9 +9,10 @@ import recursivefactorization.jl_amd as rf
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+maxdim = int(sys.argv[3]) if len(sys.argv) > 3 else 2600
 bad = 0
 for it in range(ncase):
-    m = int(rng.integers(1, 2600)); n = int(rng.integers(1, 2600))
+    m = int(rng.integers(1, maxdim)); n = int(rng.integers(1, maxdim))
     if rng.random() < 0.3: n = m
     dt = np.float64 if rng.random() < 0.7 else np.float32
     pivot = rng.random() < 0.8

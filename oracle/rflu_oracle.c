@@ -16,7 +16,8 @@
  *   src/lu.jl:153,235   TRSM call sites; arithmetic is third-party TriangularSolve.jl (compat 0.2.5,
  *                       Project.toml:23, not vendored) -> semantic restatement rfo_trsm_unit_lower_*
  *
- * Pinning status.  The reference is Julia and cannot run in the authoring container (no julia, 7 un-vendored
+ * Pinning status: PARITY UNPINNED against the reference's own outputs (neither golden vectors nor a runnable reference
+ * exist here); pinned against the reference's TEST PROPERTIES only.  The reference is Julia and cannot run in the authoring container (no julia, 7 un-vendored
  * registry dependencies), and its own tests hold NO golden vectors or known-answer L/U: test/runtests.jl checks
  * properties against LAPACK (`baselu = LinearAlgebra.lu`, :11,52) -- info equality (:15), max|L*U - A[p,:]| < 20*s*eps
  * (:19-20), solve of A[:,end] (:21-28), singular-column info (:59-64), NoPivot ipiv == 1:n (:70-84).  This oracle is

@@ -804,6 +804,16 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out)
 DEFINE_TYPED(f64, double)
 DEFINE_TYPED(f32, float)
 
+/* experiment hook (not in rflu.h): a stream restricted to an arbitrary CU mask (8 x 32 bits); the caller owns it */
+int rflu_debug_masked_stream(rflu_handle_t handle, const unsigned* mask8, void** stream_out)
+{
+    CHECK_HANDLE(handle);
+    hipStream_t st = nullptr;
+    RFLU_HIP(hipExtStreamCreateWithCUMask(&st, 8, mask8));
+    *stream_out = reinterpret_cast<void*>(st);
+    return RFLU_OK;
+}
+
 /* experiment hook (not in rflu.h): copy the RFLU_PANEL_TRACE clock stamps of the last panel launch to the host */
 int rflu_debug_panel_trace(rflu_handle_t handle, long long* out512)
 {

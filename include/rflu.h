@@ -76,7 +76,8 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out);
  *                  (`blocksize` re-read as the GPU panel width, BASELINE config 3 sweeps
  *                  64/128/256; rounded up to a multiple of 64), with one block column of lookahead: the next block
  *                  column is updated and factored while the rest of the trailing update still runs on a second stream;
- *            = 0 = library default (pure recursion below 4096 columns, block columns of 1024 with lookahead above). */
+ *            = 0 = library default, measured on MI355X: pure recursion below 1024 columns, then block columns of
+ *                  128 (<= 8192 columns), 256 (<= 12288), 512 (<= 16384), 1024 (<= 24576), 2048 above. */
 int rflu_getrf_f64(rflu_handle_t handle, int64_t m, int64_t n, double* A_host, int64_t lda, int64_t* ipiv_host,
                    int pivot, int64_t blocksize, int64_t* info);
 int rflu_getrf_f32(rflu_handle_t handle, int64_t m, int64_t n, float* A_host, int64_t lda, int64_t* ipiv_host,

@@ -490,7 +490,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     Fact<T> f{h, R, ld, m, n, ipiv, pivot};
     bool fat_tail_done = false;
     if (blocksize == 0)  // measured on MI355X (bench.py --blocksize sweep): the knee moves right with the matrix size
-        blocksize = mn < 1024 ? -1 : (mn <= 8192 ? 256 : (mn <= 16384 ? 512 : (mn <= 24576 ? 1024 : 2048)));
+        blocksize = mn < 1024 ? -1 : (mn <= 8192 ? 128 : (mn <= 12288 ? 256 : (mn <= 16384 ? 512 : (mn <= 24576 ? 1024 : 2048))));
     if (blocksize < 0 || blocksize >= mn) {
         h->last_path = RFLU_PATH_HIP_RECURSIVE;
         RFLU_TRY(f.rec(0, mn));

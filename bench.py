@@ -178,11 +178,14 @@ def main():
     # ---- roofline of the dominant kernel: one extra profiled factorization (HIP events on the launch stream) ----
     roof = None
     kern = {}
-    if single:
+    if True:
         regenerate()
         barrier()
         h.profile_enable(True)
-        step()
+        if single:
+            step()
+        else:
+            job.factor_sync()   # one block column at a time on one stream: every launch bracketed by HIP events
         barrier()
         kern = h.profile()
         h.profile_enable(False)
@@ -202,8 +205,10 @@ def main():
                     "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                     "flops_per_launch": g["work"] / g["launches"],
                     "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
-                    "note": "all GEMM launches of one profiled factorization (single-stream blocked schedule, HIP events "
-                            "on the launch stream); traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 per launch from profiles/*pmc*"}
+                    "note": ("all gemm_sub_kernel launches of one profiled factorization (single-stream blocked schedule, HIP "
+                             "events on the launch stream); traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 per launch from "
+                             "profiles/*pmc*") if single else
+                            "rank 0's gemm_sub_kernel launches of one profiled single-stream factorization (per-GPU figure)"}
 
     # ---- checks on the last factorization: residual on device (torch as an independent checker) ----
     check = {}

@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...)
 
 static int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-static int ensure_buffer(void** ptr, size_t* cap, size_t need)
+int ensure_buffer(void** ptr, size_t* cap, size_t need)
 {
     if (*cap >= need) return RFLU_OK;
     if (*ptr) RFLU_HIP(hipFree(*ptr));
@@ -93,6 +93,7 @@ static int trsm_public(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t l
     if (n <= 0 || nrhs <= 0) return RFLU_OK;
     const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB * sizeof(T);
     RFLU_TRY(ensure_buffer(&h->linv_tmp, &h->linv_tmp_bytes, need));
+    h->trsv_area = nullptr;  // the cooperative solve's exchange area shares this buffer: have it wiped before its next use
     T* li = static_cast<T*>(h->linv_tmp);
     RFLU_TRY(launch_diag_inv<T>(h, n, L, ldl, li));
     return trsm_rec<T>(h, n, nrhs, L, ldl, B, ldb, li);
@@ -120,6 +121,21 @@ static int getrs_rm(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, 
     if (ipiv) {  // rows of B follow the factorization's interchanges (NULL = NotIPIV: nothing to apply)
         RFLU_TRY(launch_perm_build(h, ipiv, 0, n, n));
         RFLU_TRY(launch_laswp<T>(h, B, ldb, 0, nrhs, 0, (n + NB - 1) / NB));
+    }
+    // few right-hand sides (<= 32: measured crossover): one cooperative launch per triangle and pass of 8 (trsv.hip)
+    // instead of ~n/32 dependent launches; many:
+    // the recursive splitting, whose GEMMs then carry the work.  RFLU_TRSV_MAX_RHS moves the crossover (0 = never).
+    static const int64_t trsv_max = [] { const char* e = getenv("RFLU_TRSV_MAX_RHS"); return e ? atoll(e) : 32ll; }();
+    if (nrhs <= trsv_max && n <= (int64_t)NB * 256 * 4) {
+        RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), h->stream));
+        RFLU_TRY(launch_trsv_coop<T>(h, n, nrhs, R, ld, B, ldb));
+        RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        RFLU_HIP(hipStreamSynchronize(h->stream));
+        if (h->info_pinned[1] != 0) {
+            set_error("cooperative solve kernel timed out waiting for a peer workgroup");
+            return RFLU_ERR_TIMEOUT;
+        }
+        return RFLU_OK;
     }
     RFLU_TRY(trsm_public<T>(h, n, nrhs, R, ld, B, ldb));
     return triu_solve_rec<T>(h, n, nrhs, R, ld, B, ldb);

@@ -73,6 +73,8 @@ struct Handle {
     int* pm_src = nullptr;
     int64_t pm_chunks = 0;
     void* linv = nullptr;        // inverses of the 64x64 diagonal blocks of L, one per leaf (pm_chunks x 64 x 64 elements)
+    unsigned trsv_tag = 0;       // last tag used by the cooperative solve (trsv.hip) in its exchange area ...
+    void* trsv_area = nullptr;   // ... which lives at this address inside linv_tmp
     void* linv_tmp = nullptr;    // same for stand-alone rflu_trsm_rm_* calls
     size_t linv_tmp_bytes = 0;
 
@@ -113,6 +115,7 @@ struct ProfScope {
 };
 
 int ensure_bookkeeping(Handle* h, int64_t rows);
+int ensure_buffer(void** ptr, size_t* cap, size_t need);  // grow-only device buffer (hipFree + hipMalloc)
 
 // ---- kernel launchers (each returns an rflu_status); all pointers are device pointers in R layout -----------------------
 template <typename T>
@@ -127,6 +130,9 @@ template <typename T>
 int launch_triu_base(Handle* h, int64_t nb, int64_t nrhs, const T* U, int64_t ldu, T* B, int64_t ldb);
 template <typename T>
 int launch_diag_inv(Handle* h, int64_t n, const T* L, int64_t ldl, T* Linv);
+// cooperative solve for few right-hand sides (trsv.hip): B <- U^-1 L^-1 B, interchanges already applied
+template <typename T>
+int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, T* B, int64_t ldb);
 template <typename T>
 int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t chunk0, int64_t chunk1);
 // apply chunks [chunk0, chunk1) to two column ranges at once: [c0, c0+ncolsA) and [c1, c1+ncolsB)

@@ -163,6 +163,22 @@ def test_pair_leaf_kernel_opt_in(shape, blocksize, dtype, monkeypatch):
     assert np.array_equal(np.asarray(G.factors)[:, -1], (2.0 ** np.arange(n)).astype(dtype))
 
 
+@pytest.mark.parametrize("n,nrhs", [(129, 8), (1000, 9), (3000, 1), (3000, 20), (4100, 64), (2000, 70), (5000, 5)])
+def test_ldiv_cooperative_and_recursive_paths(n, nrhs):
+    # up to 64 right-hand sides: one cooperative launch per triangle and pass of 8 (trsv.hip); beyond: recursive TRSM/GEMM.
+    # Same bound as runtests.jl:126-128, on a general (pivoted) matrix and through the device entry
+    A = rand_matrix(n, n, seed=900 + n)
+    B = rand_matrix(n, nrhs, seed=901 + n).copy(order="F")
+    dF = rf.lu_(to_dev_cm(A), None, True)
+    dB = to_dev_cm(B)
+    rf.ldiv_(dF, dB)
+    X = dB.cpu().numpy()
+    Xref = np.linalg.solve(A, B)
+    scale = np.linalg.norm(A, 2) * np.linalg.norm(Xref) + np.linalg.norm(B)
+    assert np.linalg.norm(A @ X - B) < 1000 * n * np.finfo(np.float64).eps * scale
+    assert np.linalg.norm(X - Xref) / np.linalg.norm(Xref) < 1e-6   # cond(rand(n,n)) ~ n: far above what we need
+
+
 def test_row_major_device_entry():
     A = rand_matrix(700, 700, seed=21)
     d = torch.from_numpy(np.ascontiguousarray(A)).to("cuda:0")

@@ -110,6 +110,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+    # RFLU_BENCH_ONE_GPU=1 (+ RFLU_BENCH_BACKEND=gloo): every rank on device 0 -- a functional rehearsal of the multi-rank
+    # path on a single-GPU box (RCCL refuses two ranks on one device); never a performance number
+    one_gpu = os.environ.get("RFLU_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dist = os.environ.get("RFLU_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with a single rank (testing)
@@ -120,7 +125,11 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("RFLU_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n = args.n or DEFAULT_N.get(args.gpus, 16384 * max(1, args.gpus // 2))
     sfx = args.dtype

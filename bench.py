@@ -160,8 +160,11 @@ def main():
     else:
         from recursivefactorization.jl_amd import distributed as D
 
+        # runs of 4 consecutive block columns per owner: 3 of 4 panel broadcasts overlap with the owner's next panel instead
+        # of sitting on the critical chain (distributed.py); RFLU_DIST_RUN overrides
+        run = int(os.environ.get("RFLU_DIST_RUN", "4" if world > 1 else "1"))
         job = D.BlockColumnLU(D.HipOps(h, sfx), n, tdt, rank, world, dev, block=args.block, pivot=bool(pivot), seed=SEED,
-                              always_broadcast=force_dist)
+                              always_broadcast=force_dist, run=run)
         regenerate = job.regenerate
         step = job.factor
 
@@ -277,7 +280,8 @@ def main():
             "config": {"workload": f"lu!(A, ipiv) of a dense uniform[0,1) {n}x{n} {'Float64' if sfx == 'f64' else 'Float32'} "
                                    f"matrix, {'partial pivoting' if pivot else 'NoPivot'}, column-major in HBM",
                        "n": n, "pivot": bool(pivot), "blocksize": args.blocksize,
-                       "layout": "single GPU" if world == 1 else f"1-D block-column cyclic over {world} GPUs",
+                       "layout": "single GPU" if world == 1 else
+                                 f"1-D block-column cyclic over {world} GPUs (block {args.block}, runs of {run})",
                        "timing": "per-step bracketed (barrier+sync both sides), input regeneration excluded"},
             "frac_of_mfma_peak": round(gflops / 1e3 / (PEAK_TFLOPS[sfx] * args.gpus), 4),
             "roofline": roof,

@@ -71,15 +71,18 @@ class HipOps:
         self.h.call(f"rflu_fill_uniform_{self.sfx}_dev", self._p(R, c0), m, w, ld, 1, seed, n_global, 0, j0, float(diag_add))
 
 
-def block_layout(n: int, block: int, world: int):
-    """[(global col start, width, owner rank, local col offset on the owner)] for every block column."""
+def block_layout(n: int, block: int, world: int, run: int = 1):
+    """[(global col start, width, owner rank, local col offset on the owner)] for every block column.
+
+    ``run`` consecutive block columns share an owner (owner = (b // run) % world): inside a run the owner goes from one
+    panel to the next without waiting for any broadcast, so only every ``run``-th broadcast is on the critical chain."""
     out = []
     nblocks = (n + block - 1) // block
     local_off = [0] * world
     for b in range(nblocks):
         j0 = b * block
         w = min(block, n - j0)
-        owner = b % world
+        owner = (b // max(run, 1)) % world
         out.append((j0, w, owner, local_off[owner]))
         local_off[owner] += w
     return out, local_off
@@ -89,14 +92,17 @@ class BlockColumnLU:
     """Factor an n x n matrix distributed by block columns.  ``factor()`` is one step of bench.py's --gpus N path."""
 
     def __init__(self, ops, n, dtype, rank, world, device, *, block=512, pivot=True, seed=12, diag_add=0.0, group=None,
-                 always_broadcast=False):
+                 always_broadcast=False, run=None):
         if block % NB:
             raise ValueError("block must be a multiple of 64")
         self.ops, self.n, self.rank, self.world, self.device = ops, n, rank, world, device
         self.block, self.pivot, self.seed, self.diag_add, self.group = block, pivot, seed, diag_add, group
         self.dtype = dtype
         self.collective = world > 1 or always_broadcast  # always_broadcast: exercise the RCCL calls with one rank
-        self.layout, local_cols = block_layout(n, block, world)
+        if run is None:
+            run = int(os.environ.get("RFLU_DIST_RUN", "1"))
+        self.run = max(1, run)
+        self.layout, local_cols = block_layout(n, block, world, self.run)
         self.n_loc = local_cols[rank]
         self.ld = max(16, (self.n_loc + 15) // 16 * 16)
         self.R = torch.zeros((n, self.ld), dtype=dtype, device=device)       # this rank's slab, row-major
@@ -220,29 +226,38 @@ class BlockColumnLU:
         ev0 = record(U)
         wait(P, ev0)
         nb = len(self.layout)
-        recv = [None] * nb
+        packed = [None] * nb   # event on P: block column b sits packed in its buffer on its owner
+        works = [None] * nb    # the asynchronous broadcasts of block column b (panel, pivots)
         done = [None] * nb
 
+        def await_works(b):
+            """Make the CURRENT stream (the host, on the CPU stand-in) wait for block column b's broadcasts."""
+            if works[b] is not None:
+                for wk in works[b]:
+                    wk.wait()
+
         def produce(b, ev_ready):
-            """On P: factor (owner) + broadcast (everybody) block column b into buffer b % 2."""
+            """On P: factor + pack (owner), then EVERY rank issues the broadcast of block column b -- asynchronously: P
+            goes on to its next panel while the transport runs; consumers wait for it where they need the data."""
             j0, w, owner, lc = self.layout[b]
             rows = n - j0
             pb, mt = self.pbuf[b % 2], self.meta[b % 2]
             panel = pb[: rows * w].view(rows, w)
             with _On(P):
                 if b >= 2:
-                    wait(P, done[b - 2])          # the buffer was last read by update b-2
+                    wait(P, done[b - 2])          # the buffer was last read by update b-2 ...
+                    await_works(b - 2)            # ... and (on its sender) by broadcast b-2
                 if self.rank == owner:
                     wait(P, ev_ready)             # this rank's slice has received update b-1
                     info = ops.panel(self.R, ld, n, j0, lc, w, self.ipiv, self.pivot)
                     panel.copy_(self.R[j0:, lc:lc + w])
                     mt[:w].copy_(self.ipiv[j0:j0 + w])
                     mt[w] = info
+                    packed[b] = record(P)
                 if self.collective:
                     src = owner if self.group is None else dist.get_global_rank(self.group, owner)
-                    dist.broadcast(panel, src=src, group=self.group)
-                    dist.broadcast(mt[: w + 1], src=src, group=self.group)
-                recv[b] = record(P)
+                    works[b] = [dist.broadcast(panel, src=src, group=self.group, async_op=True),
+                                dist.broadcast(mt[: w + 1], src=src, group=self.group, async_op=True)]
 
         produce(0, ev0)
         for b in range(nb):
@@ -252,8 +267,10 @@ class BlockColumnLU:
             nxt_slice = 0
             ev_ready = None
             with _On(U):
-                wait(U, recv[b])
-                if self.rank != owner:
+                if self.rank == owner:
+                    wait(U, packed[b])            # the owner reads its own packed copy: no need to wait for the transport
+                else:
+                    await_works(b)
                     self.ipiv[j0:j0 + w].copy_(mt[:w])
                 self.info_dev.copy_(torch.where(self.info_dev == 0, mt[w], self.info_dev))
                 if b + 1 < nb and self.rank == self.layout[b + 1][2]:
@@ -265,12 +282,12 @@ class BlockColumnLU:
                 tall_next = (b + 1 < nb and nxt_slice > 0 and n - self.layout[b + 1][0] > self.tall_rows)
             if tall_next:
                 # this rank owns a TALL block column b+1: it cannot run next to the update (not enough free CUs), and it is
-                # what every other rank will wait for -- factor and broadcast it first, whole GPU, then catch up on the
-                # bulk of update b while the others are already applying b+1
+                # what every other rank will wait for -- factor it first, whole GPU, then catch up on the bulk of update b
+                # while the others are already applying b+1
                 produce(b + 1, ev_ready)
             with _On(U):
                 if tall_next:
-                    wait(U, recv[b + 1])
+                    wait(U, packed[b + 1])
                 # (otherwise) the bulk of update b is queued BEFORE the host-blocking panel call, so the two overlap
                 if self.pivot:
                     ops.laswp(self.R, ld, n, 0, left_end, self.ipiv, j0, j0 + w)
@@ -278,6 +295,9 @@ class BlockColumnLU:
                 done[b] = record(U)
             if b + 1 < nb and not tall_next:
                 produce(b + 1, ev_ready)
+        for b in range(max(0, nb - 2), nb):   # nobody waited for the last sends on their sender
+            with _On(P):
+                await_works(b)
         if gpu:
             cur.wait_stream(U)
             cur.wait_stream(P)

@@ -24,14 +24,15 @@ def main():
     torch.cuda.set_device(dev)
     h = _ffi.Handle(0)
     h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    # (n, block, pivot, tall_rows, sync)
-    cases = [(1536, 256, True, None, False), (1536, 256, True, 700, False), (1000, 128, True, 0, False),
-             (1200, 256, False, None, False), (1536, 256, True, None, True)]
-    for (n, block, pivot, tall_rows, sync) in cases:
+    # (n, block, pivot, tall_rows, sync, run)
+    cases = [(1536, 256, True, None, False, 1), (1536, 256, True, 700, False, 1), (1000, 128, True, 0, False, 1),
+             (1200, 256, False, None, False, 1), (1536, 256, True, None, True, 1),
+             (2048, 128, True, None, False, 2), (2048, 128, True, 900, False, 4)]
+    for (n, block, pivot, tall_rows, sync, run) in cases:
         os.environ["RFLU_DIST_SYNC"] = "1" if sync else "0"
         diag = 0.0 if pivot else 10.0
         job = BlockColumnLU(HipOps(h, "f64"), n, torch.float64, rank, world, dev, block=block, pivot=pivot, seed=12,
-                            diag_add=diag)
+                            diag_add=diag, run=run)
         if tall_rows is not None:
             job.tall_rows = tall_rows
         for rep in range(2):  # twice: buffers, events and streams are reused

@@ -59,7 +59,7 @@ class NumpyOps:
         _view(R, c0, m, w, ld)[:] = blk
 
 
-def _worker(rank, world, port, n, block, pivot, diag_add, q, sync=False, tall_rows=None):
+def _worker(rank, world, port, n, block, pivot, diag_add, q, sync=False, tall_rows=None, run=1):
     if sync:
         os.environ["RFLU_DIST_SYNC"] = "1"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -69,7 +69,7 @@ def _worker(rank, world, port, n, block, pivot, diag_add, q, sync=False, tall_ro
         from recursivefactorization.jl_amd.distributed import BlockColumnLU
 
         job = BlockColumnLU(NumpyOps(), n, torch.float64, rank, world, torch.device("cpu"), block=block, pivot=pivot,
-                            seed=12, diag_add=diag_add)
+                            seed=12, diag_add=diag_add, run=run)
         if tall_rows is not None:
             job.tall_rows = tall_rows
         job.regenerate()
@@ -88,20 +88,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n,block,pivot,sync,tall_rows", [
-    (2, 300, 64, True, False, None), (3, 257, 64, True, False, None), (2, 200, 128, False, False, None),
-    (2, 300, 64, True, True, None),
-    (2, 300, 64, True, False, 150),   # block columns with more than 150 rows take the tall-panel order, the rest overlap
-    (3, 321, 64, True, False, 0),     # every block column tall
+@pytest.mark.parametrize("world,n,block,pivot,sync,tall_rows,run", [
+    (2, 300, 64, True, False, None, 1), (3, 257, 64, True, False, None, 1), (2, 200, 128, False, False, None, 1),
+    (2, 300, 64, True, True, None, 1),
+    (2, 300, 64, True, False, 150, 1),   # block columns with more than 150 rows take the tall-panel order, the rest overlap
+    (3, 321, 64, True, False, 0, 1),     # every block column tall
+    (2, 450, 64, True, False, None, 2),  # runs of two consecutive block columns per owner (broadcasts off the chain)
+    (3, 500, 64, True, False, 200, 3),   # runs of three, tall and ordinary block columns
+    (2, 450, 64, True, True, None, 2),   # the synchronous schedule on the same layout
 ])
-def test_block_column_lu_matches_single_process(world, n, block, pivot, sync, tall_rows):
+def test_block_column_lu_matches_single_process(world, n, block, pivot, sync, tall_rows, run):
     # sync=False: the lookahead schedule (panel b+1 factored and broadcast while update b is still queued; a tall panel is
     # factored by its owner before that owner's bulk update);  sync=True : one block column at a time.
     # Same collectives in the same order on every rank in all of them.
     diag_add = 0.0 if pivot else 10.0
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, block, pivot, diag_add, q, sync, tall_rows))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, block, pivot, diag_add, q, sync, tall_rows, run))
              for port in [_free_port()] for r in range(world)]
     for p in procs:
         p.start()
@@ -125,3 +128,7 @@ def test_block_layout_is_cyclic_and_complete():
     assert [o for (_, _, o, _) in layout] == [0, 1, 2, 0, 1, 2, 0, 1]
     assert sum(w for (_, w, _, _) in layout) == 1000 and sum(local) == 1000
     assert layout[3] == (384, 128, 0, 128) and layout[7] == (896, 104, 1, 256)
+    # runs of two consecutive block columns per owner
+    layout2, local2 = block_layout(1000, 128, 3, run=2)
+    assert [o for (_, _, o, _) in layout2] == [0, 0, 1, 1, 2, 2, 0, 0]
+    assert sum(local2) == 1000 and layout2[1] == (128, 128, 0, 128) and layout2[6] == (768, 128, 0, 256)

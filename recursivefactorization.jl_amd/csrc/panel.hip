@@ -44,7 +44,7 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 constexpr int AUX_SC1 = 16;
 
-constexpr unsigned PS_HDR_BYTES = 32;                       // per workgroup: {pos,tag | a_pk granule(s)}
+constexpr unsigned PS_HDR_BYTES = 64;                       // per workgroup: {pos,tag | a_pk granule(s) | next-column granule}
 constexpr unsigned PS_VAL_BYTES = 16;                       // per row value (Float32 uses the first 8)
 constexpr unsigned PS_ROW_BYTES = NB * PS_VAL_BYTES;        // per workgroup candidate row
 constexpr unsigned PS_HDR_REGION = MAX_PANEL_WGS * PS_HDR_BYTES;
@@ -80,6 +80,25 @@ struct Gran<double> {
         const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
         v = __longlong_as_double((long long)(((u64)x[0] << 32) | (u64)x[2]));
         return x[1] == tag && x[3] == tag;
+    }
+    // header of the pipelined kernel: position, pivot candidate a and the candidate row's NEXT-column entry u
+    static __device__ __forceinline__ void store_hdr3(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned pos, double a, double u) {
+        const u64 b = (u64)__double_as_longlong(a), c = (u64)__double_as_longlong(u);
+        const u4v x = {pos, tag, (unsigned)(b >> 32), tag};
+        const u4v y = {(unsigned)b, tag, (unsigned)(c >> 32), tag};
+        const u4v z = {(unsigned)c, tag, 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(y, r, off + 16, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(z, r, off + 32, 0, AUX_SC1);
+    }
+    static __device__ __forceinline__ bool load_hdr3(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned& pos, double& a, double& u) {
+        const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
+        const u4v y = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, AUX_SC1);
+        const u4v z = __builtin_amdgcn_raw_buffer_load_b128(r, off + 32, 0, AUX_SC1);
+        pos = x[0];
+        a = __longlong_as_double((long long)(((u64)x[2] << 32) | (u64)y[0]));
+        u = __longlong_as_double((long long)(((u64)y[2] << 32) | (u64)z[0]));
+        return x[1] == tag && x[3] == tag && y[1] == tag && y[3] == tag && z[1] == tag;
     }
     typedef u4v raw_t;
     static __device__ __forceinline__ raw_t load_raw(__amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -118,6 +137,20 @@ struct Gran<float> {
         const u2v x = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, AUX_SC1);
         v = __uint_as_float(x[0]);
         return x[1] == tag;
+    }
+    static __device__ __forceinline__ void store_hdr3(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned pos, float a, float u) {
+        const u4v x = {pos, tag, __float_as_uint(a), tag};
+        const u4v y = {__float_as_uint(u), tag, 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(y, r, off + 16, 0, AUX_SC1);
+    }
+    static __device__ __forceinline__ bool load_hdr3(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned& pos, float& a, float& u) {
+        const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
+        const u4v y = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, AUX_SC1);
+        pos = x[0];
+        a = __uint_as_float(x[2]);
+        u = __uint_as_float(y[0]);
+        return x[1] == tag && x[3] == tag && y[1] == tag;
     }
     typedef u2v raw_t;
     static __device__ __forceinline__ raw_t load_raw(__amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -762,6 +795,298 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_kernel(PanelArgs<T>
 }
 
 // =====================================================================================================================
+// Pipelined pivoted leaf (two or more workgroups).  The kernel above spends two DEPENDENT trips through the coherent
+// memory path per column: the headers (who wins?), then the winner's row.  Here a header also carries the candidate row's
+// NEXT-column entry u.  Once the headers of column k are in, every workgroup knows the pivot and u_{k,k+1}: it brings
+// column k+1 up to date with one multiply-add per row and starts the search for the next pivot at once -- while the
+// winner's row (columns k+2..) is still travelling.  The row is needed only when the next candidate row is published; the
+// rank-1 update of all the other rows runs behind that, next to the following header trip.
+//   per column:  poll headers(k) -> [bookkeeping, column k+1, search k+1]  ||  row(k) in flight  -> publish candidate(k+1)
+// Same arithmetic on every entry as the kernel above (each a[j] receives the same multiply-adds in the same order).
+// =====================================================================================================================
+template <typename T>
+struct PipeLds {
+    T prow[2][NB];             // pivot rows of the last two steps (columns k+2.. valid), by step parity
+    T wval[PANEL_WAVES];
+    unsigned wpos[PANEL_WAVES];
+    unsigned win[2];           // pivot position, by step parity
+    T scale[2];                // 1/pivot (1 for an exactly zero pivot)
+    T unext[2];                // winner's entry in column k+1
+    int zero[2];               // the pivot was exactly zero
+    int win_g;
+    int dead;
+    int rows[NB];
+};
+
+// search of one column inside the workgroup: 1 = this thread owns the workgroup's candidate row, 2 = no candidate at all
+// (returned to thread 0, which publishes an empty header), 0 otherwise.  One workgroup barrier.
+template <typename T>
+__device__ __forceinline__ int pipe_front(PipeLds<T>* sh, T aval, unsigned pos, bool act, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    T key = T(-1);
+    unsigned p = POS_NONE;
+    if (act) {
+        const T v = tabs(aval);
+        key = (v > T(0)) ? v : T(0);  // NaN and 0 -> 0: never preferred, ties -> lowest position (src/lu.jl:298-304)
+        p = pos;
+    }
+    wave_argmax<T>(key, p);
+    if (lane == 0) { sh->wval[wave] = key; sh->wpos[wave] = p; }
+    __syncthreads();
+    T kx[PANEL_WAVES];
+    unsigned px[PANEL_WAVES];
+#pragma unroll
+    for (int x = 0; x < PANEL_WAVES; ++x) { kx[x] = sh->wval[x]; px[x] = sh->wpos[x]; }
+    const T cv = tmax(tmax(tmax(kx[0], kx[1]), tmax(kx[2], kx[3])), tmax(tmax(kx[4], kx[5]), tmax(kx[6], kx[7])));
+    unsigned c[PANEL_WAVES];
+#pragma unroll
+    for (int x = 0; x < PANEL_WAVES; ++x) c[x] = (kx[x] == cv) ? px[x] : POS_NONE;
+    const unsigned cp = min(min(min(c[0], c[1]), min(c[2], c[3])), min(min(c[4], c[5]), min(c[6], c[7])));
+    if (act && pos == cp) return 1;
+    if (cp == POS_NONE && tid == 0) return 2;
+    return 0;
+}
+
+// flags: bit0 apply the update to this row, bit1 row still active, bit2 give up, bit3 this thread owns the workgroup's
+// candidate row for the NEXT column, bit4 (thread 0) the workgroup has no candidate for the next column
+template <typename T>
+__device__ __noinline__ MidOut<T> pipe_mid(PipeLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch, int G,
+                                           int k, int w, int r0, int g, int tid, T ak, T ak1, unsigned pos, bool act)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int par = k & 1;
+    const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(scratch);
+    const unsigned tag = epoch + (unsigned)k;
+    const unsigned base = (unsigned)par * PS_BUF_BYTES;
+    typename Gran<T>::raw_t raw;
+    bool want_row = false;
+    unsigned roff = 0;
+    RFLU_STAMP(scratch, k, 0, g, tid);
+    if (wave == 0) {
+        bool timed_out = false;
+        T gv = T(-1), ga = T(0), gu = T(0);
+        unsigned gp = POS_NONE;
+        int gg = 0;
+        for (int x = lane; x < G; x += 64) {
+            int spins = 0;
+            for (;;) {
+                unsigned xp;
+                T xv, xu;
+                asm volatile("" ::: "memory");  // plain buffer intrinsics: keep the loads inside the loop
+                if (Gran<T>::load_hdr3(rs, base + (unsigned)x * PS_HDR_BYTES, tag, xp, xv, xu)) {
+                    if (xp != POS_NONE) {
+                        const T av = tabs(xv);
+                        const T xk = (av > T(0)) ? av : T(0);
+                        if (better<T>(xk, xp, gv, gp)) { gv = xk; gp = xp; gg = x; ga = xv; gu = xu; }
+                    }
+                    break;
+                }
+                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+                if (spins > 4) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        {
+            const T mykey = gv;
+            const unsigned mypos = gp;
+            wave_argmax<T>(gv, gp);
+            const u64 who = __ballot(mykey == gv && mypos == gp && mypos != POS_NONE);
+            const int wl = who ? (__ffsll((long long)who) - 1) : 0;
+            gg = __builtin_amdgcn_readlane(gg, wl);
+            ga = readlane_val(ga, wl);
+            gu = readlane_val(gu, wl);
+        }
+        RFLU_STAMP(scratch, k, 1, g, tid);
+        if (gp != POS_NONE && lane >= k + 2 && lane < NB) {  // the winner's row: requested now, looked at after the search
+            roff = base + PS_HDR_REGION + (unsigned)gg * PS_ROW_BYTES + (unsigned)lane * PS_VAL_BYTES;
+            raw = Gran<T>::load_raw(rs, roff);
+            want_row = true;
+        }
+        if (lane == 0) {
+            sh->win_g = gg;
+            sh->win[par] = gp;
+            sh->zero[par] = (ga == T(0));
+            sh->scale[par] = (ga != T(0)) ? T(1) / ga : T(1);
+            sh->unext[par] = gu;
+        }
+        if (__any(timed_out)) {
+            if (lane == 0) {
+                __hip_atomic_store((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh->win[par] = POS_NONE;
+                sh->dead = 1;
+            }
+        }
+    }
+    __syncthreads();
+    RFLU_STAMP(scratch, k, 2, g, tid);
+    MidOut<T> o;
+    o.scale = T(1);
+    o.pos = pos;
+    o.flags = (act ? 2u : 0u) | (sh->dead ? 4u : 0u);
+    T a1 = ak1;
+    const unsigned win_pos = sh->win[par];
+    if (win_pos != POS_NONE) {
+        const unsigned kpos = (unsigned)(r0 + k);
+        if (g == 0 && tid == 0) {
+            ipiv[r0 + k] = (int64_t)win_pos + 1;
+            if (sh->zero[par] && info[0] == 0) info[0] = (int64_t)r0 + k + 1;
+        }
+        o.scale = sh->scale[par];
+        if (act) {
+            if (pos == win_pos) {
+                o.pos = kpos;      // pivot row: final position r0+k, no further updates
+                o.flags &= ~2u;
+            } else {
+                if (pos == kpos) o.pos = win_pos;  // displaced row takes the pivot's old position
+                o.flags |= 1u;
+                a1 = ak1 - (ak * o.scale) * sh->unext[par];   // column k+1 is current before the row arrives
+            }
+        }
+    }
+    if (k + 1 < w && !(o.flags & 4u)) {   // search of column k+1 (workgroup-uniform condition)
+        const int f = pipe_front<T>(sh, a1, o.pos, (o.flags & 2u) != 0, tid);
+        if (f == 1) o.flags |= 8u;
+        if (f == 2) o.flags |= 16u;
+    }
+    RFLU_STAMP(scratch, k, 3, g, tid);
+    if (wave == 0 && want_row) {
+        T xv = T(0);
+        if (!Gran<T>::unpack(raw, tag, xv)) {
+            int spins = 0;
+            for (;;) {
+                asm volatile("" ::: "memory");
+                if (Gran<T>::load(rs, roff, tag, xv)) break;
+                if (++spins > SPIN_LIMIT) {
+                    __hip_atomic_store((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh->dead = 1;
+                    break;
+                }
+            }
+        }
+        sh->prow[par][lane] = xv;
+    }
+    __syncthreads();
+    RFLU_STAMP(scratch, k, 4, g, tid);
+    if (sh->dead) o.flags |= 4u;
+    return o;
+}
+
+// publish the workgroup's candidate for column kc: header {pos, a[kc], a[kc+1]} first, then the row from column kc+2 on
+template <typename T, int KC>
+__device__ __forceinline__ void pipe_publish(const PanelArgs<T>& p, const T (&a)[NB], unsigned pos, int g)
+{
+    const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(p.scratch);
+    const unsigned tag = p.epoch + (unsigned)KC;
+    const unsigned base = (unsigned)(KC & 1) * PS_BUF_BYTES;
+    T un = T(0);
+    if constexpr (KC + 1 < NB) un = a[KC + 1];
+    Gran<T>::store_hdr3(rs, base + (unsigned)g * PS_HDR_BYTES, tag, pos, a[KC], un);
+    const unsigned roff = base + PS_HDR_REGION + (unsigned)g * PS_ROW_BYTES;
+#pragma unroll
+    for (int j = KC + 2; j < NB; ++j) Gran<T>::store(rs, roff + j * PS_VAL_BYTES, tag, a[j]);
+}
+
+template <typename T, int K>
+__device__ __forceinline__ void pipe_step(const PanelArgs<T>& p, PipeLds<T>* sh, T (&a)[NB], unsigned& pos, bool& act,
+                                          bool& dead, PermState& perm, int g, int tid)
+{
+    if (K >= p.w || dead) return;
+    T ak1 = T(0);
+    if constexpr (K + 1 < NB) ak1 = a[K + 1];
+    const MidOut<T> o = pipe_mid<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.w, p.r0, g, tid, a[K], ak1, pos, act);
+    pos = o.pos;
+    act = (o.flags & 2u) != 0;
+    dead = (o.flags & 4u) != 0;
+    if (dead) return;
+    if (g == 0 && (tid >> 6) == PANEL_WAVES - 1) {
+        const unsigned wp = sh->win[K & 1];
+        if (wp != POS_NONE) perm_state_step(perm, p.r0, K, __builtin_amdgcn_readfirstlane((int)wp), tid & 63);
+    }
+    T l = T(0);
+    if (o.flags & 1u) {
+        l = a[K] * o.scale;  // reciprocal-multiply (src/lu.jl:317-320); scale == 1 after a zero pivot
+        a[K] = l;
+        if constexpr (K + 1 < NB) a[K + 1] -= l * sh->unext[K & 1];
+    }
+    const T* prow = sh->prow[K & 1];
+    if ((o.flags & 8u) && K + 1 < p.w) {
+        // this row is the workgroup's candidate for column K+1: its header needs only the entries of columns K+1 and K+2,
+        // so it leaves first; the rest of the row follows value by value as it is updated
+        if constexpr (K + 1 < NB) {
+            const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(p.scratch);
+            const unsigned tag = p.epoch + (unsigned)(K + 1);
+            const unsigned base = (unsigned)((K + 1) & 1) * PS_BUF_BYTES;
+            T un = T(0);
+            if constexpr (K + 2 < NB) {
+                a[K + 2] -= l * prow[K + 2];
+                un = a[K + 2];
+            }
+            Gran<T>::store_hdr3(rs, base + (unsigned)g * PS_HDR_BYTES, tag, pos, a[K + 1], un);
+            const unsigned roff = base + PS_HDR_REGION + (unsigned)g * PS_ROW_BYTES;
+#pragma unroll
+            for (int j = K + 3; j < NB; ++j) {
+                a[j] -= l * prow[j];
+                Gran<T>::store(rs, roff + j * PS_VAL_BYTES, tag, a[j]);
+            }
+        }
+    } else {
+        if ((o.flags & 16u) && K + 1 < p.w)   // nobody left in this workgroup: an empty header keeps the others going
+            Gran<T>::store_hdr3(scratch_rsrc(p.scratch), (unsigned)((K + 1) & 1) * PS_BUF_BYTES + (unsigned)g * PS_HDR_BYTES,
+                                p.epoch + (unsigned)(K + 1), POS_NONE, T(0), T(0));
+        if (o.flags & 1u) {
+            if constexpr (K + 2 < NB) {
+#pragma unroll
+                for (int j = K + 2; j < NB; ++j) a[j] -= l * prow[j];
+            }
+        }
+    }
+    RFLU_STAMP(p.scratch, K, 5, g, tid);
+}
+
+template <typename T, int K0, int K1>
+struct PipeSteps {
+    static __device__ __forceinline__ void run(const PanelArgs<T>& p, PipeLds<T>* sh, T (&a)[NB], unsigned& pos,
+                                               bool& act, bool& dead, PermState& perm, int g, int tid)
+    {
+        if constexpr (K0 < K1) {
+            pipe_step<T, K0>(p, sh, a, pos, act, dead, perm, g, tid);
+            PipeSteps<T, K0 + 1, K1>::run(p, sh, a, pos, act, dead, perm, g, tid);
+        }
+    }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_pipe_kernel(PanelArgs<T> p)
+{
+    __shared__ PipeLds<T> s_lds;
+    PipeLds<T>* const sh = &s_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int row = p.r0 + g * PANEL_THREADS + tid;
+    bool act = row < p.m;
+    unsigned pos = act ? (unsigned)row : POS_NONE;
+    if (tid == 0) sh->dead = 0;
+    T a[NB];
+    load_row_direct<T>(p.R, p.ld, row, act, p.c0, p.w, a);
+    __syncthreads();
+    {   // column 0: search and publish
+        const int f = pipe_front<T>(sh, a[0], pos, act, tid);
+        if (f == 1) pipe_publish<T, 0>(p, a, pos, g);
+        if (f == 2) Gran<T>::store_hdr3(scratch_rsrc(p.scratch), (unsigned)g * PS_HDR_BYTES, p.epoch, POS_NONE, T(0), T(0));
+    }
+    bool dead = false;
+    PermState perm = perm_state_init(lane);
+    PipeSteps<T, 0, NB>::run(p, sh, a, pos, act, dead, perm, g, tid);
+    store_row_direct<T>(p.R, p.ld, pos, p.c0, p.w, a);
+    __syncthreads();
+    if (g == 0 && wave == PANEL_WAVES - 1) {
+        const int chunk = p.r0 / NB;
+        perm_state_finish(perm, p.r0, lane, sh->rows, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
+                          p.pm_src + (size_t)chunk * 2 * NB);
+    }
+}
+
+// =====================================================================================================================
 // Pair leaf: two adjacent 64-column leaves (columns [c0, c0+64) and [c0+64, c0+128)) in ONE cooperative launch.
 // Between the two leaves the recursion would run  interchanges -> 64x64 unit-lower solve -> K=64 Schur update
 // (src/lu.jl:233-240 at the lowest level) as three dependent launches; here every thread does that for its own row:
@@ -1052,7 +1377,10 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
     }
     ProfScope ps(h, RFLU_K_PANEL, (double)rows * (double)w * (double)w);
     if (pivot) {
-        hipLaunchKernelGGL((panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
+        // two or more workgroups: the pipelined kernel (RFLU_PIPE=0 selects the two-trip kernel above)
+        static const bool pipe = [] { const char* e = getenv("RFLU_PIPE"); return e == nullptr || e[0] != '0'; }();
+        if (pipe && p.G >= 2) hipLaunchKernelGGL((panel_pivot_pipe_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
+        else hipLaunchKernelGGL((panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
     } else {
         hipLaunchKernelGGL((panel_nopivot_top_kernel<T>), dim3(1), dim3(PANEL_THREADS), 0, h->stream, p);
         const int64_t below = rows - w;

@@ -9,8 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "librflu.so")
-SOURCES = ["gemm.hip", "panel.hip", "trsm.hip", "trsv.hip", "laswp.hip", "driver.cpp"]
+SOURCES = ["gemm.hip", "panel.hip", "panel_f32.hip", "trsm.hip", "trsv.hip", "laswp.hip", "driver.cpp"]
 HEADERS = ["rflu_internal.hpp", "trsm_row.hpp", os.path.join("..", "..", "include", "rflu.h")]
+EXTRA_DEPS = {"panel_f32.hip": ["panel.hip"]}  # a source that #includes another source
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
 
 
@@ -44,7 +45,7 @@ def build_librflu(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         stamp = op + ".sha1"
-        want = _digest([sp, *hdrs])
+        want = _digest([sp, *hdrs, *[os.path.join(CSRC, d) for d in EXTRA_DEPS.get(src, [])]])
         have = open(stamp).read().strip() if os.path.exists(stamp) else ""
         if force or not os.path.exists(op) or have != want:
             jobs.append((sp, op))

@@ -257,6 +257,7 @@ __device__ void perm_build_wave(const int* piv, int base, int w, int lane, int* 
     if (lane == 0) *out_cnt = total;
 }
 
+#ifndef RFLU_PANEL_F32_TU   // the non-template pieces live in the Float64 translation unit only
 __global__ void __launch_bounds__(64) perm_build_kernel(const int64_t* ipiv, int k0, int k1, int* pm_cnt, int* pm_dst,
                                                         int* pm_src)
 {
@@ -284,6 +285,7 @@ int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, in
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }
+#endif  // RFLU_PANEL_F32_TU
 
 // ---- row <-> register staging through an LDS transpose (coalesced 512-byte row segments on the memory side) -------
 template <typename T, int RT>
@@ -1418,13 +1420,17 @@ int launch_panel_pair(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }
-template int launch_panel_pair<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t*);
+// Two translation units compile this file in parallel (build.py): panel.hip itself instantiates the Float64 kernels and
+// holds the non-template functions, panel_f32.hip (#define RFLU_PANEL_F32_TU, #include "panel.hip") the Float32 kernels.
+#ifdef RFLU_PANEL_F32_TU
 template int launch_panel_pair<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t*);
-
-template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 template int launch_panel<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
+#else
+template int launch_panel_pair<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t*);
+template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 
 size_t panel_scratch_bytes() { return (PX_OFFSET_WORDS + PX_BYTES / 8) * sizeof(u64); }  // records | trace stamps | pair slots
 size_t panel_trace_offset_bytes() { return PS_TOTAL_WORDS * sizeof(u64); }
+#endif
 
 }  // namespace rflu

@@ -27,6 +27,7 @@ __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t l
                                                     int inv_cnt, const T* inv_L, T* inv_out)
 {
     __shared__ T sL[NB * NB];
+    __shared__ T sX[NB * NB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t blocksA = (ncolsA + LW_COLS - 1) / LW_COLS;
@@ -34,8 +35,8 @@ __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t l
     const int64_t blocksC = (ncolsC + LW_COLS - 1) / LW_COLS;
     if ((int64_t)blockIdx.x >= blocksA + blocksB + blocksC) {
         const int64_t i = (int64_t)blockIdx.x - (blocksA + blocksB + blocksC);
-        if (inv_nb > 0 && i < inv_cnt && threadIdx.x < 64)
-            diag_inv_block<T>(inv_nb, inv_L + i * (NB * ld + NB), ld, inv_out + i * NB * NB, sL, lane);
+        if (inv_nb > 0 && i < inv_cnt)   // workgroup-uniform
+            diag_inv_block4<T>(inv_nb, inv_L + i * (NB * ld + NB), ld, inv_out + i * NB * NB, sL, sX, threadIdx.x);
         return;
     }
     // the column ranges are covered by one launch (left and right of a panel, and a pair's first leaf)

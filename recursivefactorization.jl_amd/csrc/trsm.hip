@@ -176,13 +176,13 @@ __global__ void __launch_bounds__(256) trsm_fused_kernel(int n, int64_t nrhs, co
 // (unit diagonal explicit, zeros above it and outside nb; identity padding so that partial blocks behave).
 // Batched: block b inverts the diagonal block starting at row/column 64*b of the n x n triangle L.
 template <typename T>
-__global__ void __launch_bounds__(64) diag_inv_kernel(int n, const T* __restrict__ L, int64_t ldl, T* __restrict__ Linv_all)
+__global__ void __launch_bounds__(256) diag_inv_kernel(int n, const T* __restrict__ L, int64_t ldl, T* __restrict__ Linv_all)
 {
     __shared__ T sL[NB * NB];
-    const int j = threadIdx.x;
+    __shared__ T sX[NB * NB];
     const int b = blockIdx.x;
     const int nb = min(NB, n - b * NB);
-    diag_inv_block<T>(nb, L + (int64_t)b * NB * ldl + b * NB, ldl, Linv_all + (size_t)b * NB * NB, sL, j);
+    diag_inv_block4<T>(nb, L + (int64_t)b * NB * ldl + b * NB, ldl, Linv_all + (size_t)b * NB * NB, sL, sX, threadIdx.x);
 }
 
 // invert every 64x64 diagonal block of the n x n unit lower triangle L into Linv[0 .. ceil(n/64))
@@ -191,7 +191,7 @@ int launch_diag_inv(Handle* h, int64_t n, const T* L, int64_t ldl, T* Linv)
 {
     if (n <= 0) return RFLU_OK;
     ProfScope ps(h, RFLU_K_TRSM, (double)n * NB * NB / 3.0);
-    hipLaunchKernelGGL(diag_inv_kernel<T>, dim3((unsigned)((n + NB - 1) / NB)), dim3(64), 0, h->stream, (int)n, L, ldl, Linv);
+    hipLaunchKernelGGL(diag_inv_kernel<T>, dim3((unsigned)((n + NB - 1) / NB)), dim3(256), 0, h->stream, (int)n, L, ldl, Linv);
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }

@@ -840,6 +840,17 @@ int rflu_debug_panel_trace(rflu_handle_t handle, long long* out512)
     return RFLU_OK;
 }
 
+/* experiment hook (not in rflu.h): the all-workgroup wall-clock stamps of a -DRFLU_PANEL_TRACE_ALL build (0 words otherwise) */
+int rflu_debug_panel_trace_all(rflu_handle_t handle, long long* out, long long max_words)
+{
+    CHECK_HANDLE(handle);
+    Handle* h = H(handle);
+    RFLU_HIP(hipStreamSynchronize(h->stream));
+    const size_t nw = std::min<size_t>(panel_trace_all_words(), (size_t)std::max<long long>(max_words, 0));
+    if (nw) RFLU_HIP(hipMemcpy(out, (char*)h->pscratch + panel_trace_all_offset_bytes(), nw * sizeof(long long), hipMemcpyDeviceToHost));
+    return (int)nw;
+}
+
 int rflu_profile_enable(rflu_handle_t handle, int enable)
 {
     CHECK_HANDLE(handle);

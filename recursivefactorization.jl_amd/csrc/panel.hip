@@ -174,9 +174,18 @@ struct Gran<float> {
 
 // Optional step tracing (compile with -DRFLU_PANEL_TRACE; experiment builds only): thread 0 of workgroup 0 stores
 // clock64() stamps into the panel scratch area past the granule records.
-#ifdef RFLU_PANEL_TRACE
+#if defined(RFLU_PANEL_TRACE_ALL)
+// every workgroup's thread 0 (first 32 workgroups), wall clock (100 MHz, common to all CUs): skew between workgroups
+#define RFLU_TRACE_ALL_WORDS (32 * (NB + 1) * 8)
+#define RFLU_STAMP(scratch, k, i, g, tid) do { if ((g) < 32 && (tid) == 0) ((long long*)((scratch) + PX_OFFSET_WORDS + PX_BYTES / 8))[((g) * (NB + 1) + (k)) * 8 + (i)] = (long long)wall_clock64(); } while (0)
+#define RFLU_STAMP_ANY(scratch, k, i, g) do { if ((g) < 32) ((long long*)((scratch) + PX_OFFSET_WORDS + PX_BYTES / 8))[((g) * (NB + 1) + (k)) * 8 + (i)] = (long long)wall_clock64(); } while (0)
+#elif defined(RFLU_PANEL_TRACE)
+#define RFLU_TRACE_ALL_WORDS 0
+#define RFLU_STAMP_ANY(scratch, k, i, g) do { } while (0)
 #define RFLU_STAMP(scratch, k, i, g, tid) do { if ((g) == 0 && (tid) == 0) ((long long*)((scratch) + PS_TOTAL_WORDS))[(k) * 8 + (i)] = clock64(); } while (0)
 #else
+#define RFLU_TRACE_ALL_WORDS 0
+#define RFLU_STAMP_ANY(scratch, k, i, g) do { } while (0)
 #define RFLU_STAMP(scratch, k, i, g, tid) do { } while (0)
 #endif
 
@@ -820,6 +829,14 @@ struct PipeLds {
     int rows[NB];
 };
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory counter,
+// i.e. it would make wave 0 sit out the round trip of the row request it has just issued -- the very latency the pipelined
+// kernel wants to hide behind the search (scripts/panel_skew_trace.py: 400 ns at barrier 1 with __syncthreads()).
+__device__ __forceinline__ void barrier_lds_only()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // search of one column inside the workgroup: 1 = this thread owns the workgroup's candidate row, 2 = no candidate at all
 // (returned to thread 0, which publishes an empty header), 0 otherwise.  One workgroup barrier.
 template <typename T>
@@ -835,7 +852,7 @@ __device__ __forceinline__ int pipe_front(PipeLds<T>* sh, T aval, unsigned pos, 
     }
     wave_argmax<T>(key, p);
     if (lane == 0) { sh->wval[wave] = key; sh->wpos[wave] = p; }
-    __syncthreads();
+    barrier_lds_only();
     T kx[PANEL_WAVES];
     unsigned px[PANEL_WAVES];
 #pragma unroll
@@ -919,7 +936,7 @@ __device__ __noinline__ MidOut<T> pipe_mid(PipeLds<T>* sh, u64* scratch, int64_t
             }
         }
     }
-    __syncthreads();
+    barrier_lds_only();   // the row request above stays in flight
     RFLU_STAMP(scratch, k, 2, g, tid);
     MidOut<T> o;
     o.scale = T(1);
@@ -1011,35 +1028,37 @@ __device__ __forceinline__ void pipe_step(const PanelArgs<T>& p, PipeLds<T>* sh,
         if constexpr (K + 1 < NB) a[K + 1] -= l * sh->unext[K & 1];
     }
     const T* prow = sh->prow[K & 1];
-    if ((o.flags & 8u) && K + 1 < p.w) {
-        // this row is the workgroup's candidate for column K+1: its header needs only the entries of columns K+1 and K+2,
-        // so it leaves first; the rest of the row follows value by value as it is updated
-        if constexpr (K + 1 < NB) {
-            const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(p.scratch);
-            const unsigned tag = p.epoch + (unsigned)(K + 1);
-            const unsigned base = (unsigned)((K + 1) & 1) * PS_BUF_BYTES;
-            T un = T(0);
-            if constexpr (K + 2 < NB) {
-                a[K + 2] -= l * prow[K + 2];
-                un = a[K + 2];
-            }
+    const bool upd = (o.flags & 1u) != 0;
+    const bool cand = (o.flags & 8u) != 0 && K + 1 < p.w;   // this row is the workgroup's candidate for column K+1
+    if constexpr (K + 1 < NB) {
+        // Everybody brings column K+2 up to date (one multiply-add), then the candidate's header leaves BEFORE any of the
+        // long update loops: inside a divergent if/else hipcc ran the other 63 lanes' update first and the header waited
+        // ~450 ns for it (scripts/panel_skew_trace.py: barrier 3 -> header out 744 ns).
+        const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(p.scratch);
+        const unsigned tag = p.epoch + (unsigned)(K + 1);
+        const unsigned base = (unsigned)((K + 1) & 1) * PS_BUF_BYTES;
+        T un = T(0);
+        if constexpr (K + 2 < NB) {
+            if (upd) a[K + 2] -= l * prow[K + 2];
+            un = a[K + 2];
+        }
+        if (cand) {
             Gran<T>::store_hdr3(rs, base + (unsigned)g * PS_HDR_BYTES, tag, pos, a[K + 1], un);
+            RFLU_STAMP_ANY(p.scratch, K, 6, g);
+        } else if ((o.flags & 16u) && K + 1 < p.w) {   // nobody left in this workgroup: an empty header keeps the others going
+            Gran<T>::store_hdr3(rs, base + (unsigned)g * PS_HDR_BYTES, tag, POS_NONE, T(0), T(0));
+        }
+        asm volatile("" ::: "memory");   // keep the header store ahead of the loops below
+        if (cand) {
             const unsigned roff = base + PS_HDR_REGION + (unsigned)g * PS_ROW_BYTES;
 #pragma unroll
             for (int j = K + 3; j < NB; ++j) {
                 a[j] -= l * prow[j];
                 Gran<T>::store(rs, roff + j * PS_VAL_BYTES, tag, a[j]);
             }
-        }
-    } else {
-        if ((o.flags & 16u) && K + 1 < p.w)   // nobody left in this workgroup: an empty header keeps the others going
-            Gran<T>::store_hdr3(scratch_rsrc(p.scratch), (unsigned)((K + 1) & 1) * PS_BUF_BYTES + (unsigned)g * PS_HDR_BYTES,
-                                p.epoch + (unsigned)(K + 1), POS_NONE, T(0), T(0));
-        if (o.flags & 1u) {
-            if constexpr (K + 2 < NB) {
+        } else if (upd) {
 #pragma unroll
-                for (int j = K + 2; j < NB; ++j) a[j] -= l * prow[j];
-            }
+            for (int j = K + 3; j < NB; ++j) a[j] -= l * prow[j];
         }
     }
     RFLU_STAMP(p.scratch, K, 5, g, tid);
@@ -1429,7 +1448,9 @@ template int launch_panel<float>(Handle*, float*, int64_t, int64_t, int64_t, int
 template int launch_panel_pair<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t*);
 template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 
-size_t panel_scratch_bytes() { return (PX_OFFSET_WORDS + PX_BYTES / 8) * sizeof(u64); }  // records | trace stamps | pair slots
+size_t panel_scratch_bytes() { return (PX_OFFSET_WORDS + PX_BYTES / 8 + RFLU_TRACE_ALL_WORDS) * sizeof(u64); }  // records | trace stamps | pair slots | all-workgroup trace
+size_t panel_trace_all_offset_bytes() { return (PX_OFFSET_WORDS + PX_BYTES / 8) * sizeof(u64); }
+size_t panel_trace_all_words() { return RFLU_TRACE_ALL_WORDS; }
 size_t panel_trace_offset_bytes() { return PS_TOTAL_WORDS * sizeof(u64); }
 #endif
 

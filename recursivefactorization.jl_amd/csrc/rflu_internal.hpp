@@ -147,6 +147,8 @@ int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64
 int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, int64_t m);
 size_t panel_scratch_bytes();
 size_t panel_trace_offset_bytes();
+size_t panel_trace_all_offset_bytes();
+size_t panel_trace_all_words();
 template <typename T>
 int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0, int64_t w, int64_t* ipiv, int pivot);
 template <typename T>

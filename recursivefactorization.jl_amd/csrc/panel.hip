@@ -821,10 +821,7 @@ struct PipeLds {
     T wval[PANEL_WAVES];
     unsigned wpos[PANEL_WAVES];
     unsigned win[2];           // pivot position, by step parity
-    T scale[2];                // 1/pivot (1 for an exactly zero pivot)
     T unext[2];                // winner's entry in column k+1
-    int zero[2];               // the pivot was exactly zero
-    int win_g;
     int dead;
     int rows[NB];
 };
@@ -882,75 +879,72 @@ __device__ __noinline__ MidOut<T> pipe_mid(PipeLds<T>* sh, u64* scratch, int64_t
     bool want_row = false;
     unsigned roff = 0;
     RFLU_STAMP(scratch, k, 0, g, tid);
-    if (wave == 0) {
-        bool timed_out = false;
-        T gv = T(-1), ga = T(0), gu = T(0);
-        unsigned gp = POS_NONE;
-        int gg = 0;
-        for (int x = lane; x < G; x += 64) {
-            int spins = 0;
-            for (;;) {
-                unsigned xp;
-                T xv, xu;
-                asm volatile("" ::: "memory");  // plain buffer intrinsics: keep the loads inside the loop
-                if (Gran<T>::load_hdr3(rs, base + (unsigned)x * PS_HDR_BYTES, tag, xp, xv, xu)) {
-                    if (xp != POS_NONE) {
-                        const T av = tabs(xv);
-                        const T xk = (av > T(0)) ? av : T(0);
-                        if (better<T>(xk, xp, gv, gp)) { gv = xk; gp = xp; gg = x; ga = xv; gu = xu; }
-                    }
-                    break;
+    // EVERY wave polls the headers and reduces them on its own: no hand-over through LDS, no barrier before the bookkeeping
+    bool timed_out = false;
+    T gv = T(-1), ga = T(0), gu = T(0);
+    unsigned gp = POS_NONE;
+    int gg = 0;
+    for (int x = lane; x < G; x += 64) {
+        int spins = 0;
+        for (;;) {
+            unsigned xp;
+            T xv, xu;
+            asm volatile("" ::: "memory");  // plain buffer intrinsics: keep the loads inside the loop
+            if (Gran<T>::load_hdr3(rs, base + (unsigned)x * PS_HDR_BYTES, tag, xp, xv, xu)) {
+                if (xp != POS_NONE) {
+                    const T av = tabs(xv);
+                    const T xk = (av > T(0)) ? av : T(0);
+                    if (better<T>(xk, xp, gv, gp)) { gv = xk; gp = xp; gg = x; ga = xv; gu = xu; }
                 }
-                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
-                if (spins > 4) __builtin_amdgcn_s_sleep(1);
+                break;
             }
+            if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+            if (spins > 4) __builtin_amdgcn_s_sleep(1);
         }
-        {
-            const T mykey = gv;
-            const unsigned mypos = gp;
-            wave_argmax<T>(gv, gp);
-            const u64 who = __ballot(mykey == gv && mypos == gp && mypos != POS_NONE);
-            const int wl = who ? (__ffsll((long long)who) - 1) : 0;
-            gg = __builtin_amdgcn_readlane(gg, wl);
-            ga = readlane_val(ga, wl);
-            gu = readlane_val(gu, wl);
+    }
+    {
+        const T mykey = gv;
+        const unsigned mypos = gp;
+        wave_argmax<T>(gv, gp);
+        const u64 who = __ballot(mykey == gv && mypos == gp && mypos != POS_NONE);
+        const int wl = who ? (__ffsll((long long)who) - 1) : 0;
+        gg = __builtin_amdgcn_readlane(gg, wl);
+        ga = readlane_val(ga, wl);
+        gu = readlane_val(gu, wl);
+    }
+    RFLU_STAMP(scratch, k, 1, g, tid);
+    if (__any(timed_out)) {
+        gp = POS_NONE;
+        if (lane == 0) {
+            __hip_atomic_store((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh->dead = 1;
         }
-        RFLU_STAMP(scratch, k, 1, g, tid);
+    }
+    if (wave == 0) {
         if (gp != POS_NONE && lane >= k + 2 && lane < NB) {  // the winner's row: requested now, looked at after the search
             roff = base + PS_HDR_REGION + (unsigned)gg * PS_ROW_BYTES + (unsigned)lane * PS_VAL_BYTES;
             raw = Gran<T>::load_raw(rs, roff);
             want_row = true;
         }
-        if (lane == 0) {
-            sh->win_g = gg;
+        if (lane == 0) {   // for the caller (read after the barriers below)
             sh->win[par] = gp;
-            sh->zero[par] = (ga == T(0));
-            sh->scale[par] = (ga != T(0)) ? T(1) / ga : T(1);
             sh->unext[par] = gu;
         }
-        if (__any(timed_out)) {
-            if (lane == 0) {
-                __hip_atomic_store((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh->win[par] = POS_NONE;
-                sh->dead = 1;
-            }
-        }
     }
-    barrier_lds_only();   // the row request above stays in flight
     RFLU_STAMP(scratch, k, 2, g, tid);
     MidOut<T> o;
     o.scale = T(1);
     o.pos = pos;
-    o.flags = (act ? 2u : 0u) | (sh->dead ? 4u : 0u);
+    o.flags = act ? 2u : 0u;
     T a1 = ak1;
-    const unsigned win_pos = sh->win[par];
+    const unsigned win_pos = gp;
     if (win_pos != POS_NONE) {
         const unsigned kpos = (unsigned)(r0 + k);
         if (g == 0 && tid == 0) {
             ipiv[r0 + k] = (int64_t)win_pos + 1;
-            if (sh->zero[par] && info[0] == 0) info[0] = (int64_t)r0 + k + 1;
+            if (ga == T(0) && info[0] == 0) info[0] = (int64_t)r0 + k + 1;
         }
-        o.scale = sh->scale[par];
+        o.scale = (ga != T(0)) ? T(1) / ga : T(1);
         if (act) {
             if (pos == win_pos) {
                 o.pos = kpos;      // pivot row: final position r0+k, no further updates
@@ -958,11 +952,11 @@ __device__ __noinline__ MidOut<T> pipe_mid(PipeLds<T>* sh, u64* scratch, int64_t
             } else {
                 if (pos == kpos) o.pos = win_pos;  // displaced row takes the pivot's old position
                 o.flags |= 1u;
-                a1 = ak1 - (ak * o.scale) * sh->unext[par];   // column k+1 is current before the row arrives
+                a1 = ak1 - (ak * o.scale) * gu;   // column k+1 is current before the row arrives
             }
         }
     }
-    if (k + 1 < w && !(o.flags & 4u)) {   // search of column k+1 (workgroup-uniform condition)
+    if (k + 1 < w) {   // search of column k+1 (workgroup-uniform condition; a timed-out workgroup still meets its barriers)
         const int f = pipe_front<T>(sh, a1, o.pos, (o.flags & 2u) != 0, tid);
         if (f == 1) o.flags |= 8u;
         if (f == 2) o.flags |= 16u;
@@ -1398,9 +1392,10 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
     }
     ProfScope ps(h, RFLU_K_PANEL, (double)rows * (double)w * (double)w);
     if (pivot) {
-        // two or more workgroups: the pipelined kernel (RFLU_PIPE=0 selects the two-trip kernel above)
+        // 2..64 workgroups: the pipelined kernel, in which every wave polls one header per lane (RFLU_PIPE=0 selects the
+        // two-trip kernel above, which also serves taller panels: measured 0.5 % faster there)
         static const bool pipe = [] { const char* e = getenv("RFLU_PIPE"); return e == nullptr || e[0] != '0'; }();
-        if (pipe && p.G >= 2) hipLaunchKernelGGL((panel_pivot_pipe_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
+        if (pipe && p.G >= 2 && p.G <= 64) hipLaunchKernelGGL((panel_pivot_pipe_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
         else hipLaunchKernelGGL((panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
     } else {
         hipLaunchKernelGGL((panel_nopivot_top_kernel<T>), dim3(1), dim3(PANEL_THREADS), 0, h->stream, p);

@@ -1,5 +1,6 @@
 """Per-phase cycle breakdown of the pivoted panel kernel (needs librflu_trace.so built with -DRFLU_PANEL_TRACE)."""
 import ctypes, sys, os
+os.environ["RFLU_PIPE"] = "0"   # this script reads the stamps of the two-trip kernel (panel_pipe_trace.py: the pipelined one)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from recursivefactorization.jl_amd import _ffi

@@ -36,7 +36,8 @@ enum rflu_status {
     RFLU_ERR_ARG = 1,      /* bad argument (negative size, lda < m, NULL pointer, unsupported size) */
     RFLU_ERR_HIP = 2,      /* a HIP runtime call failed */
     RFLU_ERR_TIMEOUT = 3,  /* the cooperative panel kernel gave up waiting for a peer workgroup */
-    RFLU_ERR_NODEVICE = 4  /* no usable gfx950 device */
+    RFLU_ERR_NODEVICE = 4, /* no usable gfx950 device */
+    RFLU_ERR_PLACEMENT = 5 /* a workgroup of the XCD-local panel kernel ran on an unexpected XCD (results discarded) */
 };
 
 /* rflu_last_path values: which implementation served the last getrf call on this handle.  The analogue of the

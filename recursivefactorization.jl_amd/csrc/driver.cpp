@@ -197,6 +197,22 @@ static int getrs_host(Handle* h, int64_t n, int64_t nrhs, const T* F, int64_t ld
     return RFLU_OK;
 }
 
+// error flags raised by the cooperative kernels (info_dev[1], copied to info_pinned[1] by the caller)
+static int panel_flags_status(Handle* h)
+{
+    const int64_t f = h->info_pinned[1];
+    if (f & 2) {
+        set_error("a workgroup of the XCD-local panel kernel ran on an unexpected XCD; results discarded "
+                  "(set RFLU_PANEL_LOCAL=0 to use the placement-independent kernel)");
+        return RFLU_ERR_PLACEMENT;
+    }
+    if (f != 0) {
+        set_error("cooperative panel kernel timed out waiting for a peer workgroup");
+        return RFLU_ERR_TIMEOUT;
+    }
+    return RFLU_OK;
+}
+
 template <typename T>
 struct Fact {
     Handle* h;
@@ -533,10 +549,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
 
     RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     RFLU_HIP(hipStreamSynchronize(h->stream));
-    if (h->info_pinned[1] != 0) {
-        set_error("cooperative panel kernel timed out waiting for a peer workgroup");
-        return RFLU_ERR_TIMEOUT;
-    }
+    RFLU_TRY(panel_flags_status(h));
     *info = h->info_pinned[0];
     return RFLU_OK;
 }
@@ -656,6 +669,8 @@ int rflu_create(rflu_handle_t* handle, int device)
     RFLU_HIP(hipMemset(h->pscratch, 0, h->pscratch_bytes));
     RFLU_HIP(hipEventCreate(&h->ev0));
     RFLU_HIP(hipEventCreate(&h->ev1));
+    if (const char* e = getenv("RFLU_PANEL_LOCAL")) h->panel_local = atoi(e);
+    if (const char* e = getenv("RFLU_PANEL_LOCAL_MAXG")) h->panel_local_maxg = atoi(e);
     *handle = reinterpret_cast<rflu_handle_t>(h);
     return RFLU_OK;
 }
@@ -753,7 +768,7 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out)
         }                                                                                                             \
         RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream)); \
         RFLU_HIP(hipStreamSynchronize(h->stream));                                                                    \
-        if (h->info_pinned[1] != 0) { set_error("cooperative panel kernel timed out"); return RFLU_ERR_TIMEOUT; }     \
+        RFLU_TRY(panel_flags_status(h));                                                                              \
         *info = h->info_pinned[0];                                                                                    \
         return RFLU_OK;                                                                                               \
     }                                                                                                                 \

@@ -82,7 +82,12 @@ struct Handle {
     unsigned long long* pscratch = nullptr;
     size_t pscratch_bytes = 0;
     unsigned epoch = 1;          // next unused granule tag
-    int64_t* info_dev = nullptr; // [0] = info, [1] = panel error flag
+    int64_t* info_dev = nullptr; // [0] = info, [1] = panel error flags (bit0 timeout, bit1 XCD placement mismatch)
+    // XCD-local leaf kernel (panel_local.hip): 0 = off, 1 = on (participants = blocks b % 8 == panel_xcc of an 8*G grid,
+    // plain-store records), 2 = the same kernel with sc1 records on any placement
+    int panel_local = 0;
+    int panel_local_maxg = 32;
+    int panel_xcc = 0;
     int64_t* info_pinned = nullptr;
 
     // timers

@@ -1,0 +1,42 @@
+"""Per-column time of one cooperative leaf (m x 64, Float64) for the panel kernel variants, alone on the GPU, and a
+bit-for-bit comparison of their results.  RFLU_PANEL_LOCAL: 0 = pipelined sc1 kernel (panel.hip), 1 = XCD-local kernel
+(panel_local.hip, plain-store records on one XCD), 2 = the same kernel with sc1 records on any placement.
+usage: python scripts/panel_bench.py [m ...]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from recursivefactorization.jl_amd import _ffi
+
+sizes = [int(x) for x in sys.argv[1:]] or [1024, 2048, 4096, 8192, 15872, 16384]
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+modes = [int(x) for x in os.environ.get("PANEL_MODES", "0,1,2").split(",")]
+dtype = torch.float32 if os.environ.get("PANEL_F32") else torch.float64
+sfx = "f32" if dtype == torch.float32 else "f64"
+ref = {}
+for mode in modes:
+    os.environ["RFLU_PANEL_LOCAL"] = str(mode)
+    h = _ffi.Handle(0)
+    h.set_stream(None)
+    for m in sizes:
+        torch.manual_seed(m)
+        A0 = torch.rand((m, 64), dtype=dtype, device="cuda")
+        ip = torch.zeros(m, dtype=torch.int64, device="cuda")
+        info = ctypes.c_int64(0)
+        reps = 12
+        for it in range(reps + 3):
+            if it == 3:
+                h.profile_enable(True)
+            A = A0.clone()
+            h.call(f"rflu_panel_rm_{sfx}_dev", m, 0, 0, 64, P(A), 64, P(ip), 1, ctypes.byref(info))
+        pr = h.profile()["panel"]
+        h.profile_enable(False)
+        us = pr["ms"] * 1e3 / pr["launches"]
+        key = (m,)
+        same = ""
+        if key in ref:
+            rA, rip = ref[key]
+            same = f"  bit-identical to mode {modes[0]}: A {bool(torch.equal(rA, A))} ipiv {bool(torch.equal(rip, ip[:64]))}"
+        else:
+            ref[key] = (A.clone(), ip[:64].clone())
+        print(f"mode {mode} m={m:6d} G={(m + 511) // 512:3d}: {us:8.1f} us per leaf = {us / 64 * 1000:7.0f} ns per column  info={info.value}{same}", flush=True)
+    h.close()

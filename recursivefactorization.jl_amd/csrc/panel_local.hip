@@ -24,20 +24,6 @@
 namespace rflu {
 
 template <typename T>
-struct LocalLds {
-    T prow[2][NB];             // pivot rows of the last two steps (columns k+2.. valid), by step parity
-    T crow[NB];                // staging of this workgroup's candidate row for the coalesced publish
-    unsigned whi[PANEL_WAVES]; // per-wave candidate: integer key (high / low word) and row position
-    unsigned wlo[PANEL_WAVES];
-    unsigned wpos[PANEL_WAVES];
-    unsigned win[2];           // pivot position, by step parity
-    T scale[2];                // 1 / pivot (1 when the pivot is exactly zero)
-    T wu[2];                   // the pivot row's entry in column k+1
-    int dead;
-    int rows[NB];
-};
-
-template <typename T>
 struct LocalArgs {
     PanelArgs<T> p;
     int stride;     // !LOCAL: participants are the blocks with blockIdx % stride == sel
@@ -95,55 +81,63 @@ struct IKey<float> {
 
 // 64-lane reductions with the gfx9 row-broadcast DPP modes: after the four intra-row stages row_bcast15 / row_bcast31
 // carry the row results upward; lane 63 holds the total
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ unsigned dpp_keep(unsigned v)
-{
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false);
-}
+// (hand-written: hipcc emits v_mov / s_nop / v_mov_dpp / v_max per stage where ONE v_max_u32_dpp does the stage; the s_nop 1
+// covers the two wait states between a VALU write and a DPP read of the same register)
 __device__ __forceinline__ unsigned wave_max_b(unsigned v)
 {
-    v = max(v, dpp_keep<0xB1, 0xF>(v));
-    v = max(v, dpp_keep<0x4E, 0xF>(v));
-    v = max(v, dpp_keep<0x141, 0xF>(v));
-    v = max(v, dpp_keep<0x140, 0xF>(v));
-    v = max(v, dpp_keep<0x142, 0xA>(v));
-    v = max(v, dpp_keep<0x143, 0xC>(v));
+    asm volatile(
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_b(unsigned v)
 {
-    v = min(v, dpp_keep<0xB1, 0xF>(v));
-    v = min(v, dpp_keep<0x4E, 0xF>(v));
-    v = min(v, dpp_keep<0x141, 0xF>(v));
-    v = min(v, dpp_keep<0x140, 0xF>(v));
-    v = min(v, dpp_keep<0x142, 0xA>(v));
-    v = min(v, dpp_keep<0x143, 0xC>(v));
+    asm volatile(
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // Every lane passes (hi, lo, pos); pos == POS_NONE marks a lane without a candidate (its hi / lo must be 0).
 // Returns wave-uniform: the best key in (hi, lo), its position in pos (POS_NONE: no candidate at all) and the lane that
 // holds it (0 if none).
+// The common case needs ONE reduction: the high words (sign-free exponent + 20 mantissa bits for Float64) of two rows of a
+// wave almost never coincide at the maximum; only then the low words and, for exact ties, the positions are reduced too.
 template <bool TWO>
 __device__ __forceinline__ int wave_argmax_i(unsigned& hi, unsigned& lo, unsigned& pos)
 {
     const unsigned mh = wave_max_b(hi);
     bool hit = (hi == mh) && (pos != POS_NONE);
-    unsigned ml = 0u;
-    if (TWO) {
-        ml = wave_max_b((hi == mh) ? lo : 0u);
-        hit = hit && (lo == ml);
-    }
     u64 mask = __ballot(hit);
-    unsigned p = POS_NONE;
+    unsigned p = POS_NONE, ml = 0u;
     int wl = 0;
     if (mask != 0) {
-        if (__popcll(mask) != 1) {   // exact ties: the lowest position among the lanes holding the maximum
-            p = wave_min_b(hit ? pos : POS_NONE);
-            mask = __ballot(hit && pos == p);
+        if (__popcll(mask) != 1) {
+            if (TWO) {
+                ml = wave_max_b(hit ? lo : 0u);
+                hit = hit && (lo == ml);
+                mask = __ballot(hit);
+            }
+            if (__popcll(mask) != 1) {   // exact ties: the lowest position among the lanes holding the maximum
+                p = wave_min_b(hit ? pos : POS_NONE);
+                mask = __ballot(hit && pos == p);
+            }
         }
         wl = __ffsll((long long)mask) - 1;
         p = (unsigned)__builtin_amdgcn_readlane((int)pos, wl);
+        ml = (unsigned)__builtin_amdgcn_readlane((int)lo, wl);
     }
     hi = mh;
     lo = ml;
@@ -151,243 +145,345 @@ __device__ __forceinline__ int wave_argmax_i(unsigned& hi, unsigned& lo, unsigne
     return wl;
 }
 
-// wave-level part of the column search: this wave's best (key, pos) goes to LDS
+// =====================================================================================================================
+// The pipeline.  Column c's pivot needs a full all-to-all exchange; everything else is arranged so that between two
+// exchanges the threads execute as few dependent instructions as possible (two waves share a SIMD: every wave instruction on
+// the chain costs ~8 clocks, and the old kernels ran ~850 of them per column on every wave):
+//   * H(c), the header a workgroup publishes for column c, = {position, a_c, a_{c+1}, l_{c-1}} of its candidate row, where
+//     a_c has received eliminations 0..c-1, a_{c+1} only 0..c-2, and l_{c-1} is the row's multiplier of elimination c-1.  The
+//     reader completes the lagging entry itself: u_{c,c+1} = a_{c+1} - l_{c-1} * P_{c-1}[c+1] (P_{c-1} = pivot row c-1, which
+//     every workgroup holds) -- the same multiply-add, with the same operands, the owner applies to its own register later.
+//     So a header never waits for the previous pivot row.
+//   * Rw(c), the candidate's row record, = entries j >= c+2 with a_{c+2} through elimination c-1 and a_{j>=c+3} through c-2;
+//     the reader finishes them the same way: P_c[j] = Rw(c)[j] - (j >= c+3 ? l_{c-1} * P_{c-1}[j] : 0).  The owner learns
+//     that it is its workgroup's candidate one barrier after the header left and publishes the row then (one coalesced
+//     store of its wave, staged through LDS); nobody waits for it before the next barrier A.
+//   * per step, all threads:  barrier A(c) -> read {pivot position, 1/pivot, u_{c,c+1}} from LDS -> deferred multiply-adds
+//     of elimination c-1 on the two entries the next record needs -> interchange bookkeeping, l_c, a_{c+1} -> wave argmax
+//     (integer keys, DPP) -> the wave's record {key, position, a_{c+1}, a_{c+2}, l_c} to LDS -> barrier B(c) -> the rest of
+//     elimination c-1 (off the chain, next to the exchange).
+//   * per step, wave 0 only (alone on the chain, raised priority): after B(c) combine the 8 wave records, publish H(c+1),
+//     finish P_c, poll the G headers H(c+1), reduce, divide once, hand over through LDS -> barrier A(c+1).
+// Every entry receives exactly the multiply-adds of the unblocked algorithm in the same order: results are bit-identical
+// to panel_pivot_kernel / panel_pivot_pipe_kernel.
+// =====================================================================================================================
 template <typename T>
-__device__ __forceinline__ void local_front_wave(LocalLds<T>* sh, T aval, unsigned pos, bool act, int tid)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    unsigned hi, lo, p = act ? pos : POS_NONE;
-    IKey<T>::split(aval, act, hi, lo);
-    wave_argmax_i<IKey<T>::TWO>(hi, lo, p);
-    if (lane == 0) { sh->whi[wave] = hi; sh->wlo[wave] = lo; sh->wpos[wave] = p; }
-}
-
-// after the barrier: 1 = this thread owns the workgroup's candidate row, 2 = (thread 0) no candidate at all, 0 otherwise.
-// Lane l looks at the record of wave l & 7 (duplicates change nothing), one more wave reduction picks the winner.
-template <typename T>
-__device__ __forceinline__ int local_front_combine(LocalLds<T>* sh, unsigned pos, bool act, int tid)
-{
-    const int r = tid & (PANEL_WAVES - 1);
-    unsigned hi = sh->whi[r], lo = sh->wlo[r], cp = sh->wpos[r];
-    wave_argmax_i<IKey<T>::TWO>(hi, lo, cp);
-    if (act && pos == cp) return 1;
-    if (cp == POS_NONE && tid == 0) return 2;
-    return 0;
-}
-
-// the candidate row staged in LDS (columns kc+2..) leaves as ONE coalesced store of the candidate's wave
-template <typename T, int AUX>
-__device__ __noinline__ void local_publish_row(LocalLds<T>* sh, u64* scratch, unsigned epoch, int kc, int g, int lane)
-{
-    scratch = uni(scratch);
-    epoch = uni(epoch);
-    kc = uni(kc);
-    g = uni(g);
-    if (lane >= kc + 2 && lane < NB) {
-        const T v = sh->crow[lane];
-        const unsigned roff = (unsigned)(kc & 1) * PS_BUF_BYTES + PS_HDR_REGION + (unsigned)g * PS_ROW_BYTES;
-        Gran<T>::template store<AUX>(scratch_rsrc(scratch), roff + (unsigned)lane * PS_VAL_BYTES, epoch + (unsigned)kc, v);
+struct Hdr4;
+template <>
+struct Hdr4<double> {
+    template <int AUX>
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned pos, double a,
+                                                 double a1, double l)
+    {
+        const u64 A = (u64)__double_as_longlong(a), B = (u64)__double_as_longlong(a1), L = (u64)__double_as_longlong(l);
+        const u4v g0 = {pos, tag, (unsigned)(A >> 32), tag};
+        const u4v g1 = {(unsigned)A, tag, (unsigned)(B >> 32), tag};
+        const u4v g2 = {(unsigned)B, tag, (unsigned)(L >> 32), tag};
+        const u4v g3 = {(unsigned)L, tag, 0u, tag};
+        __builtin_amdgcn_raw_buffer_store_b128(g0, r, off, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(g1, r, off + 16, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(g2, r, off + 32, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(g3, r, off + 48, 0, AUX);
     }
+    static __device__ __forceinline__ bool load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned& pos, double& a,
+                                                double& a1, double& l)
+    {
+        const u4v g0 = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
+        const u4v g1 = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, AUX_SC1);
+        const u4v g2 = __builtin_amdgcn_raw_buffer_load_b128(r, off + 32, 0, AUX_SC1);
+        const u4v g3 = __builtin_amdgcn_raw_buffer_load_b128(r, off + 48, 0, AUX_SC1);
+        pos = g0[0];
+        a = __longlong_as_double((long long)(((u64)g0[2] << 32) | (u64)g1[0]));
+        a1 = __longlong_as_double((long long)(((u64)g1[2] << 32) | (u64)g2[0]));
+        l = __longlong_as_double((long long)(((u64)g2[2] << 32) | (u64)g3[0]));
+        const unsigned ok = (g0[1] ^ tag) | (g0[3] ^ tag) | (g1[1] ^ tag) | (g1[3] ^ tag) | (g2[1] ^ tag) | (g2[3] ^ tag) |
+                            (g3[1] ^ tag) | (g3[3] ^ tag);
+        return ok == 0u;
+    }
+};
+template <>
+struct Hdr4<float> {
+    template <int AUX>
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned pos, float a,
+                                                 float a1, float l)
+    {
+        const u4v g0 = {pos, tag, __float_as_uint(a), tag};
+        const u4v g1 = {__float_as_uint(a1), tag, __float_as_uint(l), tag};
+        __builtin_amdgcn_raw_buffer_store_b128(g0, r, off, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(g1, r, off + 16, 0, AUX);
+    }
+    static __device__ __forceinline__ bool load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, unsigned& pos, float& a,
+                                                float& a1, float& l)
+    {
+        const u4v g0 = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX_SC1);
+        const u4v g1 = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, AUX_SC1);
+        pos = g0[0];
+        a = __uint_as_float(g0[2]);
+        a1 = __uint_as_float(g1[0]);
+        l = __uint_as_float(g1[2]);
+        return ((g0[1] ^ tag) | (g0[3] ^ tag) | (g1[1] ^ tag) | (g1[3] ^ tag)) == 0u;
+    }
+};
+
+template <typename T>
+struct XHand {          // what wave 0 hands to the other waves at barrier A(c)
+    T scale;            // 1 / pivot (1 when the pivot is exactly zero)
+    T wu;               // u_{c,c+1}
+    T p1, p2;           // P_{c-1}[c+1], P_{c-1}[c+2]: what the two chain entries still miss (one LDS round trip for all)
+    unsigned win;       // the pivot's row position (POS_NONE: no candidate anywhere)
+    unsigned cpos;      // position of THIS workgroup's candidate for column c (its owner publishes Rw(c))
+};
+
+template <typename T>
+struct XLds {
+    T prow[2][NB];             // P_c by parity of c (entries j >= c+2)
+    T crow[NB];                // staging of the candidate row for the coalesced publish
+    XHand<T> hand[2];          // by parity of c
+    T ra1[PANEL_WAVES];        // per-wave records of the search for column c+1
+    T ra2[PANEL_WAVES];
+    T rl[PANEL_WAVES];
+    unsigned rhi[PANEL_WAVES];
+    unsigned rlo[PANEL_WAVES];
+    unsigned rpos[PANEL_WAVES];
+    T w0_lh[2];                // wave 0: l^H of the winner of column c (finishes P_c), by parity of c
+    int w0_wl[2];              // wave 0: workgroup of the winner of column c
+    int dead;
+    int rows[NB];
+};
+
+// All waves, between the bookkeeping of column c and barrier B(c): search of column c+1 inside the wave; lane 0 leaves the
+// wave's record {key, position, a_{c+1}, a_{c+2}, l_c of the winning lane}.
+template <typename T>
+__device__ __forceinline__ void x_record(XLds<T>* sh, int tid, T a1, T a2, T l, unsigned pos, bool act)
+{
+    const int lane = tid & 63, wave = uni(tid >> 6);
+    if (wave < PANEL_WAVES) {
+        unsigned hi, lo, p = act ? pos : POS_NONE;
+        IKey<T>::split(a1, act, hi, lo);
+        unsigned mh = hi, ml = lo;
+        const int wl = wave_argmax_i<IKey<T>::TWO>(mh, ml, p);
+        if (lane == wl) {   // the winning lane leaves the record itself (lane 0 an empty one if the wave has no candidate)
+            sh->rhi[wave] = mh;
+            sh->rlo[wave] = ml;
+            sh->rpos[wave] = p;
+            sh->ra1[wave] = a1;
+            sh->ra2[wave] = a2;
+            sh->rl[wave] = l;
+        }
+    }
+    barrier_lds_only();   // B
 }
 
-// header of column kc: {position, a[kc], a[kc+1]} of the workgroup's candidate, or an empty header
+// Communication wave after barrier B(c): the workgroup's candidate for column c+1 from the 8 wave records; its header leaves at once.
 template <typename T, int AUX>
-__device__ __noinline__ void local_publish_header(u64* scratch, unsigned epoch, int kc, int g, unsigned pos, T a0, T a1)
+__device__ __forceinline__ void x_w0_publish(XLds<T>* sh, u64* scratch, unsigned epoch, int c1, int g, int lane)
 {
     scratch = uni(scratch);
     epoch = uni(epoch);
-    kc = uni(kc);
+    c1 = uni(c1);
     g = uni(g);
-    Gran<T>::template store_hdr3<AUX>(scratch_rsrc(scratch), (unsigned)(kc & 1) * PS_BUF_BYTES + (unsigned)g * PS_HDR_BYTES,
-                                      epoch + (unsigned)kc, pos, a0, a1);
+    const int r = lane & (PANEL_WAVES - 1);
+    const bool has = lane < PANEL_WAVES;   // lanes 0..7 hold the 8 wave records
+    unsigned hi = has ? sh->rhi[r] : 0u, lo = has ? sh->rlo[r] : 0u, cp = has ? sh->rpos[r] : POS_NONE;
+    const T a1 = sh->ra1[r], a2 = sh->ra2[r], l = sh->rl[r];
+    const int wl = wave_argmax_i<IKey<T>::TWO>(hi, lo, cp);
+    if (lane == wl)   // the lane that holds the winning record (an empty header if there is no candidate: cp == POS_NONE)
+        Hdr4<T>::template store<AUX>(scratch_rsrc(scratch), (unsigned)(c1 & 1) * PS_BUF_BYTES + (unsigned)g * PS_HDR_BYTES,
+                                     epoch + (unsigned)c1, cp, a1, a2, l);
+    if (lane == 0) sh->hand[c1 & 1].cpos = cp;
+    if (c1 >= 1) RFLU_STAMP(scratch, c1 - 1, 6, g, lane);
 }
 
-// One column, everything that needs no static register index.
-//   wave 0: poll the G headers of column k (lane x = header x), reduce them to the pivot, request the pivot row, divide,
-//           hand {pos, 1/pivot, u} over in LDS
-//   barrier A
-//   all   : bookkeeping for the thread's row, column k+1 brought up to date, wave-level search of column k+1
-//   wave 0: the pivot row (columns k+2..) lands in LDS
-//   barrier B
-//   all   : workgroup candidate of column k+1
-// flags: bit0 apply the update to this row, bit1 row still active, bit2 give up, bit3 this thread owns the workgroup's
-// candidate row for the NEXT column, bit4 (thread 0) the workgroup has no candidate for the next column
+// Communication wave before barrier A(c1): finish P_c (c = c1-1) from the winner's row record, poll the G headers of column c1,
+// reduce, complete u_{c1,c1+1}, divide, hand over.
 template <typename T>
-__device__ __noinline__ MidOut<T> local_mid(LocalLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch,
-                                            int G, int k, int w, int r0, int g, int tid, T ak, T ak1, unsigned pos, bool act)
+__device__ __forceinline__ void x_w0_exchange(XLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch, int G,
+                                           int c1, int r0, int g, int lane)
 {
     scratch = uni(scratch);
     info = uni(info);
     ipiv = uni(ipiv);
     epoch = uni(epoch);
     G = uni(G);
-    k = uni(k);
-    w = uni(w);
+    c1 = uni(c1);
     r0 = uni(r0);
     g = uni(g);
-    const int lane = tid & 63, wave = uni(tid >> 6);
-    const int par = k & 1;
     const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(scratch);
-    const unsigned tag = epoch + (unsigned)k;
-    const unsigned base = (unsigned)par * PS_BUF_BYTES;
-    RFLU_STAMP(scratch, k, 0, g, tid);
-    typename Gran<T>::raw_t raw;
-    bool want_row = false;
-    unsigned roff = 0;
-    if (wave == 0) {
-        bool timed_out = false;
-        unsigned xp = POS_NONE;
-        T xa = T(0), xu = T(0);
-        if (lane < G) {
+    const int c = c1 - 1;
+    bool timed_out = false;
+    T pc = T(0);   // P_c[lane]
+    if (c >= 0) {
+        const int wlc = uni(sh->w0_wl[c & 1]);
+        const T lh = sh->w0_lh[c & 1];
+        if (wlc >= 0 && lane >= c + 2 && lane < NB) {
+            const unsigned roff = (unsigned)(c & 1) * PS_BUF_BYTES + PS_HDR_REGION + (unsigned)wlc * PS_ROW_BYTES +
+                                  (unsigned)lane * PS_VAL_BYTES;
+            T xv = T(0);
             int spins = 0;
             for (;;) {
-                asm volatile("" ::: "memory");  // plain buffer intrinsics: keep the loads inside the loop
-                if (Gran<T>::load_hdr3(rs, base + (unsigned)lane * PS_HDR_BYTES, tag, xp, xa, xu)) break;
-                if (++spins > SPIN_LIMIT) { timed_out = true; xp = POS_NONE; break; }
+                asm volatile("" ::: "memory");  // plain buffer intrinsics: keep the load inside the loop
+                if (Gran<T>::load(rs, roff, epoch + (unsigned)c, xv)) break;
+                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
             }
+            // entries j >= c+3 still miss elimination c-1 of the (then) candidate row
+            if (c >= 1 && lane >= c + 3) xv -= lh * sh->prow[(c - 1) & 1][lane];
+            pc = xv;
+            sh->prow[c & 1][lane] = xv;
         }
-        unsigned hi, lo, gp = xp;
-        IKey<T>::split(xa, xp != POS_NONE, hi, lo);
-        const int wl = wave_argmax_i<IKey<T>::TWO>(hi, lo, gp);   // the winner's lane is its workgroup index
-        const T ga = readlane_val(xa, wl), gu = readlane_val(xu, wl);
-        if (__any(timed_out)) {
-            gp = POS_NONE;
-            if (lane == 0) {
-                __hip_atomic_fetch_or((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh->dead = 1;
-            }
+    }
+    // ---- the headers of column c1: lane x = workgroup x
+    unsigned xp = POS_NONE;
+    T xa = T(0), xa1 = T(0), xl = T(0);
+    if (lane < G) {
+        const unsigned hoff = (unsigned)(c1 & 1) * PS_BUF_BYTES + (unsigned)lane * PS_HDR_BYTES;
+        int spins = 0;
+        for (;;) {
+            asm volatile("" ::: "memory");
+            if (Hdr4<T>::load(rs, hoff, epoch + (unsigned)c1, xp, xa, xa1, xl)) break;
+            if (++spins > SPIN_LIMIT) { timed_out = true; xp = POS_NONE; break; }
         }
-        if (gp != POS_NONE && lane >= k + 2 && lane < NB) {  // the pivot row: requested now, looked at after the search
-            roff = base + PS_HDR_REGION + (unsigned)wl * PS_ROW_BYTES + (unsigned)lane * PS_VAL_BYTES;
-            raw = Gran<T>::load_raw(rs, roff);
-            want_row = true;
-        }
-        const T sc = (ga != T(0)) ? T(1) / ga : T(1);   // once per workgroup instead of once per thread
+    }
+    unsigned hi, lo, gp = xp;
+    IKey<T>::split(xa, xp != POS_NONE, hi, lo);
+    const int wl = wave_argmax_i<IKey<T>::TWO>(hi, lo, gp);   // the winner's lane is its workgroup index
+    const T ga = readlane_val(xa, wl), ga1 = readlane_val(xa1, wl), gl = readlane_val(xl, wl);
+    T gu = ga1;
+    if (c >= 0 && c1 + 1 < NB) gu = ga1 - gl * readlane_val(pc, c1 + 1);   // u_{c1,c1+1}: the entry misses elimination c
+    if (__any(timed_out)) {
+        gp = POS_NONE;
         if (lane == 0) {
-            sh->win[par] = gp;
-            sh->scale[par] = sc;
-            sh->wu[par] = gu;
-            if (g == 0 && gp != POS_NONE) {
-                ipiv[r0 + k] = (int64_t)gp + 1;
-                if (ga == T(0) && info[0] == 0) info[0] = (int64_t)r0 + k + 1;
-            }
+            __hip_atomic_fetch_or((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh->dead = 1;
         }
     }
-    barrier_lds_only();   // A: the pivot is known to every wave (wave 0's row request stays in flight)
-    RFLU_STAMP(scratch, k, 1, g, tid);
-    const unsigned win_pos = sh->win[par];
-    MidOut<T> o;
-    o.scale = sh->scale[par];
-    o.pos = pos;
-    o.flags = act ? 2u : 0u;
-    T a1 = ak1;
-    if (win_pos != POS_NONE) {
-        const unsigned kpos = (unsigned)(r0 + k);
-        if (act) {
-            if (pos == win_pos) {
-                o.pos = kpos;      // pivot row: final position r0+k, no further updates
-                o.flags &= ~2u;
-            } else {
-                if (pos == kpos) o.pos = win_pos;  // displaced row takes the pivot's old position
-                o.flags |= 1u;
-                a1 = ak1 - (ak * o.scale) * sh->wu[par];   // column k+1 is current before the row arrives
-            }
+    const T sc = (ga != T(0)) ? T(1) / ga : T(1);   // once per workgroup
+    const T p1 = readlane_val(pc, (c1 + 1) & 63), p2 = readlane_val(pc, (c1 + 2) & 63);   // P_c[c1+1], P_c[c1+2]
+    if (lane == 0) {
+        XHand<T>* h = &sh->hand[c1 & 1];
+        h->scale = sc;
+        h->wu = gu;
+        h->p1 = p1;
+        h->p2 = p2;
+        h->win = gp;
+        sh->w0_lh[c1 & 1] = gl;
+        sh->w0_wl[c1 & 1] = (gp != POS_NONE) ? wl : -1;
+        if (g == 0 && gp != POS_NONE) {
+            ipiv[r0 + c1] = (int64_t)gp + 1;
+            if (ga == T(0) && info[0] == 0) info[0] = (int64_t)r0 + c1 + 1;
         }
     }
-    const bool more = k + 1 < w;   // workgroup-uniform
-    if (more) local_front_wave<T>(sh, a1, o.pos, (o.flags & 2u) != 0, tid);
-    RFLU_STAMP(scratch, k, 2, g, tid);
-    if (wave == 0 && want_row) {
-        T xv = T(0);
-        if (!Gran<T>::unpack(raw, tag, xv)) {
-            int spins = 0;
-            for (;;) {
-                asm volatile("" ::: "memory");
-                if (Gran<T>::load(rs, roff, tag, xv)) break;
-                if (++spins > SPIN_LIMIT) {
-                    __hip_atomic_fetch_or((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sh->dead = 1;
-                    break;
-                }
-            }
-        }
-        sh->prow[par][lane] = xv;
-    }
-    barrier_lds_only();   // B: wave records of column k+1 and the pivot row of column k are in LDS
-    RFLU_STAMP(scratch, k, 3, g, tid);
-    if (more) {
-        const int f = local_front_combine<T>(sh, o.pos, (o.flags & 2u) != 0, tid);
-        if (f == 1) o.flags |= 8u;
-        if (f == 2) o.flags |= 16u;
-    }
-    if (sh->dead) o.flags |= 4u;
-    RFLU_STAMP(scratch, k, 4, g, tid);
-    return o;
+    if (c1 >= 1) RFLU_STAMP(scratch, c1 - 1, 7, g, lane);
 }
 
-template <typename T, int K, int AUX>
-__device__ __forceinline__ void local_step(const PanelArgs<T>& p, LocalLds<T>* sh, T (&a)[NB], unsigned& pos, bool& act,
-                                           bool& dead, PermState& perm, int g, int tid)
+// the candidate row staged in LDS (entries c+2..) leaves as ONE coalesced store of the owner's wave
+template <typename T, int AUX>
+__device__ __forceinline__ void x_publish_row(XLds<T>* sh, u64* scratch, unsigned epoch, int c, int g, int lane)
 {
-    if (K >= p.w || dead) return;
-    T ak1 = T(0);
-    if constexpr (K + 1 < NB) ak1 = a[K + 1];
-    const MidOut<T> o = local_mid<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.w, p.r0, g, tid, a[K], ak1, pos, act);
-    pos = o.pos;
-    act = (o.flags & 2u) != 0;
-    dead = (o.flags & 4u) != 0;
-    if (dead) return;
-    if (g == 0 && (tid >> 6) == PANEL_WAVES - 1) {
-        const unsigned wp = sh->win[K & 1];
-        if (wp != POS_NONE) perm_state_step(perm, p.r0, K, __builtin_amdgcn_readfirstlane((int)wp), tid & 63);
+    scratch = uni(scratch);
+    epoch = uni(epoch);
+    c = uni(c);
+    g = uni(g);
+    if (lane >= c + 2 && lane < NB) {
+        const T v = sh->crow[lane];
+        const unsigned roff = (unsigned)(c & 1) * PS_BUF_BYTES + PS_HDR_REGION + (unsigned)g * PS_ROW_BYTES;
+        Gran<T>::template store<AUX>(scratch_rsrc(scratch), roff + (unsigned)lane * PS_VAL_BYTES, epoch + (unsigned)c, v);
     }
-    const T* prow = sh->prow[K & 1];
-    const bool upd = (o.flags & 1u) != 0;
-    const bool more = K + 1 < p.w;                      // workgroup-uniform
-    const bool cand = more && (o.flags & 8u) != 0;      // this row is the workgroup's candidate for column K+1
-    T l = T(0);
-    if (upd) {
-        l = a[K] * o.scale;  // reciprocal-multiply (src/lu.jl:317-320); scale == 1 after a zero pivot
-        a[K] = l;
-        if constexpr (K + 1 < NB) a[K + 1] -= l * sh->wu[K & 1];
-        if constexpr (K + 2 < NB) a[K + 2] -= l * prow[K + 2];
-    }
-    if constexpr (K + 1 < NB) {
-        // the header of column K+1 leaves before the long update loop
-        T un = T(0);
-        if constexpr (K + 2 < NB) un = a[K + 2];
-        if (cand) local_publish_header<T, AUX>(p.scratch, p.epoch, K + 1, g, pos, a[K + 1], un);
-        else if (more && (o.flags & 16u)) local_publish_header<T, AUX>(p.scratch, p.epoch, K + 1, g, POS_NONE, T(0), T(0));
-        RFLU_STAMP(p.scratch, K, 6, g, tid);
-    }
-    if constexpr (K + 3 < NB) {
-        if (upd) {
-#pragma unroll
-            for (int j = K + 3; j < NB; ++j) a[j] -= l * prow[j];
-        }
-        if (cand) {
-#pragma unroll
-            for (int j = K + 3; j < NB; ++j) sh->crow[j] = a[j];
-        }
-        if (__ballot(cand) != 0) local_publish_row<T, AUX>(sh, p.scratch, p.epoch, K + 1, g, tid & 63);
-    }
-    RFLU_STAMP(p.scratch, K, 5, g, tid);
 }
 
-template <typename T, int K0, int K1, int AUX>
-struct LocalSteps {
-    static __device__ __forceinline__ void run(const PanelArgs<T>& p, LocalLds<T>* sh, T (&a)[NB], unsigned& pos,
-                                               bool& act, bool& dead, PermState& perm, int g, int tid)
+struct XState {
+    unsigned pos;
+    bool act;
+    bool updprev;   // elimination c-1 still has to reach this row's entries j >= c+1
+    bool dead;
+};
+
+// Step C >= 0: column C.  C == -1 is the prologue: records of column 0, H(0), first exchange.
+template <typename T, int C, int AUX>
+__device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a)[NB], T& lprev, XState& st, PermState& perm,
+                                       int g, int tid)
+{
+    if (C >= p.w || st.dead) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    bool owner = false;
+    T l = T(0);
+    bool upd = false;
+    if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 0, g, tid);
+    if constexpr (C >= 0) {
+        const XHand<T> h = sh->hand[C & 1];
+        if (sh->dead) { st.dead = true; return; }
+        owner = st.pos == h.cpos && st.pos != POS_NONE;
+        if constexpr (C >= 1) {
+            if (st.updprev) {   // elimination C-1 on the two entries the next record needs
+                if constexpr (C + 1 < NB) a[C + 1] -= lprev * h.p1;
+                if constexpr (C + 2 < NB) a[C + 2] -= lprev * h.p2;
+            }
+        }
+        if (h.win != POS_NONE && st.act) {
+            const unsigned kpos = (unsigned)(p.r0 + C);
+            if (st.pos == h.win) {
+                st.pos = kpos;      // pivot row: final position r0+C, no further updates
+                st.act = false;
+            } else {
+                if (st.pos == kpos) st.pos = h.win;   // displaced row takes the pivot's old position
+                upd = true;
+                l = a[C] * h.scale;   // reciprocal-multiply (src/lu.jl:317-320); scale == 1 after a zero pivot
+                a[C] = l;
+                if constexpr (C + 1 < NB) a[C + 1] -= l * h.wu;
+            }
+        }
+        if (g == 0 && wave == PANEL_WAVES - 1 && h.win != POS_NONE)
+            perm_state_step(perm, p.r0, C, __builtin_amdgcn_readfirstlane((int)h.win), lane);
+    }
+    const bool more = C + 1 < p.w;   // workgroup-uniform
+    if constexpr (C + 1 < NB) {
+        if (more) {
+            T a2 = T(0);
+            if constexpr (C + 2 < NB) a2 = a[C + 2];
+            if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 1, g, tid);
+            x_record<T>(sh, tid, a[C + 1], a2, l, st.pos, st.act);   // ends with barrier B
+            if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 2, g, tid);
+            if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 3, g, tid);
+        }
+    }
+    if constexpr (C >= 0 && C + 2 < NB) {
+        if (owner) {   // Rw(C): a[C+2] has elimination C-1, the rest C-2 (the deferred loop below has not run yet)
+#pragma unroll
+            for (int j = C + 2; j < NB; ++j) sh->crow[j] = a[j];
+        }
+        if (__ballot(owner) != 0) x_publish_row<T, AUX>(sh, p.scratch, p.epoch, C, g, lane);
+    }
+    if constexpr (C >= 1 && C + 3 < NB) {
+        if (st.updprev) {   // the rest of elimination C-1
+            const T* P = sh->prow[(C - 1) & 1];
+#pragma unroll
+            for (int j = C + 3; j < NB; ++j) a[j] -= lprev * P[j];
+        }
+    }
+    lprev = l;
+    st.updprev = upd;
+    if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 4, g, tid);
+    if constexpr (C + 1 < NB) {
+        if (more) {
+            if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 5, g, tid);
+            barrier_lds_only();   // A(C+1)
+        }
+    }
+}
+
+template <typename T, int C0, int C1, int AUX>
+struct XSteps {
+    static __device__ __forceinline__ void run(const PanelArgs<T>& p, XLds<T>* sh, T (&a)[NB], T& lprev, XState& st,
+                                               PermState& perm, int g, int tid)
     {
-        if constexpr (K0 < K1) {
-            local_step<T, K0, AUX>(p, sh, a, pos, act, dead, perm, g, tid);
-            LocalSteps<T, K0 + 1, K1, AUX>::run(p, sh, a, pos, act, dead, perm, g, tid);
+        if constexpr (C0 < C1) {
+            x_step<T, C0, AUX>(p, sh, a, lprev, st, perm, g, tid);
+            XSteps<T, C0 + 1, C1, AUX>::run(p, sh, a, lprev, st, perm, g, tid);
         }
     }
 };
 
 template <typename T, bool LOCAL>
-__global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_local_kernel(LocalArgs<T> la)
+__global__ void __launch_bounds__(PANEL_THREADS + 64) panel_pivot_local_kernel(LocalArgs<T> la)
 {
     constexpr int AUX = LOCAL ? 0 : AUX_SC1;
     // LOCAL: the participants are the blocks that RUN on the chosen XCD.  A launch spreads its blocks round-robin over the
@@ -396,32 +492,42 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_local_kernel(LocalA
     // differently a participant is missing and the bounded spins end the launch with the timeout flag.
     if (LOCAL ? ((int)hw_xcc_id() != la.want_xcc) : ((int)(blockIdx.x % (unsigned)la.stride) != la.sel)) return;
     const PanelArgs<T>& p = la.p;
-    __shared__ LocalLds<T> s_lds;
-    LocalLds<T>* const sh = &s_lds;
+    __shared__ XLds<T> s_lds;
+    XLds<T>* const sh = &s_lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = (int)(blockIdx.x / (unsigned)la.stride);
     const int row = p.r0 + g * PANEL_THREADS + tid;
-    bool act = row < p.m;
-    unsigned pos = act ? (unsigned)row : POS_NONE;
-    if (tid == 0) sh->dead = 0;
-    T a[NB];
-    load_row_direct<T>(p.R, p.ld, row, act, p.c0, p.w, a);
-    {   // column 0: search and publish
-        local_front_wave<T>(sh, a[0], pos, act, tid);
-        __syncthreads();
-        const int f = local_front_combine<T>(sh, pos, act, tid);
-        if (f == 1) {
-            local_publish_header<T, AUX>(p.scratch, p.epoch, 0, g, pos, a[0], a[1]);
-#pragma unroll
-            for (int j = 2; j < NB; ++j) sh->crow[j] = a[j];
-        }
-        if (f == 2) local_publish_header<T, AUX>(p.scratch, p.epoch, 0, g, POS_NONE, T(0), T(0));
-        if (__ballot(f == 1) != 0) local_publish_row<T, AUX>(sh, p.scratch, p.epoch, 0, g, lane);
+    // waves 0..7 own one matrix row per thread; wave 8 is the communication wave (no rows): it alone runs the exchange, at
+    // raised priority, so none of that sits on a wave that also has row work to do
+    if (wave == PANEL_WAVES) __builtin_amdgcn_s_setprio(3);
+    XState st;
+    st.act = row < p.m && wave < PANEL_WAVES;
+    st.pos = st.act ? (unsigned)row : POS_NONE;
+    st.updprev = false;
+    st.dead = false;
+    if (tid == 0) {
+        sh->dead = 0;
+        sh->w0_wl[0] = sh->w0_wl[1] = -1;
     }
-    bool dead = false;
+    T a[NB];
+    load_row_direct<T>(p.R, p.ld, row, st.act, p.c0, p.w, a);
+    __syncthreads();
+    T lprev = T(0);
     PermState perm = perm_state_init(lane);
-    LocalSteps<T, 0, NB, AUX>::run(p, sh, a, pos, act, dead, perm, g, tid);
-    store_row_direct<T>(p.R, p.ld, pos, p.c0, p.w, a);
+    if (wave == PANEL_WAVES) {
+        // communication wave: a run-time loop (no row registers, no static indices), everything inline -- a non-inlined
+        // call would wait for the acknowledgement of the stores just issued (s_waitcnt vmcnt(0) at every call boundary)
+        for (int c1 = 0; c1 < p.w; ++c1) {
+            barrier_lds_only();   // B(c1 - 1): the wave records of column c1 are in LDS
+            x_w0_publish<T, AUX>(sh, p.scratch, p.epoch, c1, g, lane);
+            x_w0_exchange<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, c1, p.r0, g, lane);
+            barrier_lds_only();   // A(c1)
+            if (sh->dead) break;
+        }
+    } else {
+        XSteps<T, -1, NB, AUX>::run(p, sh, a, lprev, st, perm, g, tid);
+        store_row_direct<T>(p.R, p.ld, st.pos, p.c0, p.w, a);
+    }
     __syncthreads();
     if (g == 0 && wave == PANEL_WAVES - 1) {
         const int chunk = p.r0 / NB;
@@ -441,8 +547,8 @@ int launch_panel_local(Handle* h, const PanelArgs<T>& p, int stride, int sel, in
     la.sel = sel;
     la.want_xcc = want_xcc;
     const dim3 grid((unsigned)(p.G * stride));
-    if (local) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true>), grid, dim3(PANEL_THREADS), 0, h->stream, la);
-    else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false>), grid, dim3(PANEL_THREADS), 0, h->stream, la);
+    if (local) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true>), grid, dim3(PANEL_THREADS + 64), 0, h->stream, la);
+    else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false>), grid, dim3(PANEL_THREADS + 64), 0, h->stream, la);
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }

@@ -72,7 +72,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 }
 
 // grid = G * stride workgroups; participants are blocks b with b % stride == 0 (stride 8 => all on XCD 0)
-template <int SA, int LA, int THREADS>
+template <int SA, int LA, int THREADS, int UNROLL = 1, int NOPS = 0>
 __global__ void __launch_bounds__(THREADS) allstep(unsigned* buf, long long* out, int G, int stride, int steps, int local_work)
 {
     if (blockIdx.x % stride != 0) return;
@@ -87,7 +87,9 @@ __global__ void __launch_bounds__(THREADS) allstep(unsigned* buf, long long* out
     unsigned acc = (unsigned)(g * 977 + tid);
     const long long w0 = wall_clock64();
     int bad = 0;
+#pragma unroll UNROLL
     for (int s = 1; s <= steps; ++s) {
+        if (NOPS == 300) asm volatile(".rept 300\n s_nop 0\n .endr" ::: "memory");   // code volume only (1.2 KB, ~300 clocks)
         // local search: wave argmax, LDS, barrier, combine
         unsigned key = acc * 2654435761u + (unsigned)s;
         if (local_work) {
@@ -150,31 +152,42 @@ static void run_pp(unsigned* buf, long long* out, const char* name, int p)
     fflush(stdout);
 }
 
-template <int SA, int LA, int THREADS>
+template <int SA, int LA, int THREADS, int UNROLL = 1, int NOPS = 0>
 static void run_all(unsigned* buf, long long* out, const char* name, int G, int stride, int local_work)
 {
-    const int steps = 4000;
+    const int steps = 4032;
     hipMemset(buf, 0, 1 << 20);
     hipMemset(out, 0, 4096);
-    allstep<SA, LA, THREADS><<<G * stride, THREADS>>>(buf, out, G, stride, steps, local_work);
+    allstep<SA, LA, THREADS, UNROLL, NOPS><<<G * stride, THREADS>>>(buf, out, G, stride, steps, local_work);
     hipError_t e = hipDeviceSynchronize();
     std::vector<long long> h(8 + 64);
     hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
     int nx[16] = {0};
     for (int g = 0; g < G && g < 64; ++g) nx[h[8 + g] & 15]++;
-    printf("allstep  %-22s T=%4d G=%2d stride=%d local=%d: %7.1f ns/step  bad=%lld  xcc histogram:", name, THREADS, G, stride,
+    printf("allstep  %-22s T=%4d U=%2d nops=%3d G=%2d stride=%d local=%d: %7.1f ns/step  bad=%lld  xcc histogram:", name, THREADS, UNROLL, NOPS, G, stride,
            local_work, (double)h[0] * 10.0 / steps, h[1]);
     for (int x = 0; x < 8; ++x) printf(" %d", nx[x]);
     printf(" %s\n", e == hipSuccess ? "" : "ERROR");
     fflush(stdout);
 }
 
-int main()
+int main(int argc, char** argv)
 {
     unsigned* buf;
     long long* out;
     hipMalloc(&buf, 1 << 20);
     hipMalloc(&out, 4096);
+    if (argc > 1) {   // instruction-fetch experiment: the same step looped (hot I-cache) vs 64 distinct copies (> 64 KB, cold)
+        for (int rep = 0; rep < 2; ++rep) {
+            run_all<0, 16, 512, 1, 0>(buf, out, "looped", 32, 8, 1);
+            run_all<0, 16, 512, 1, 300>(buf, out, "looped + 300 nops", 32, 8, 1);
+            run_all<0, 16, 512, 64, 0>(buf, out, "64 copies", 32, 8, 1);
+            run_all<0, 16, 512, 64, 300>(buf, out, "64 copies + 300 nops", 32, 8, 1);
+            run_all<0, 16, 512, 1, 300>(buf, out, "looped + 300 nops", 2, 8, 1);
+            run_all<0, 16, 512, 64, 300>(buf, out, "64 copies + 300 nops", 2, 8, 1);
+        }
+        return 0;
+    }
     for (int p : {8, 1}) {
         run_pp<16, 16>(buf, out, "st sc1 / ld sc1", p);
         run_pp<0, 16>(buf, out, "st plain / ld sc1", p);

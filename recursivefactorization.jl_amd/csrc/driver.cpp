@@ -302,9 +302,12 @@ int get_ustream(Handle* h, int reserve, hipStream_t* out)
     if (!h->ustreams[r]) {
         // CU mask bits are enumerated round-robin over the 8 XCDs (scripts/probes/cumask.hip): bits 0..31 are 4 CUs of
         // every XCD, and so on.  A mask that empties an XCD is ignored by the runtime, so whole 32-bit words are cleared.
+        // The mask covers the CUs the device actually reports (num_cus / 32 words); callers only ask for a reservation
+        // on a full 256-CU device (factor_lookahead).
         uint32_t mask[8];
-        for (int i = 0; i < 8; ++i) mask[i] = (i < r) ? 0u : 0xffffffffu;
-        if (hipExtStreamCreateWithCUMask(&h->ustreams[r], 8, mask) != hipSuccess) {
+        const int words = std::min(8, (h->num_cus + 31) / 32);
+        for (int i = 0; i < 8; ++i) mask[i] = (i < r || i >= words) ? 0u : 0xffffffffu;
+        if (words <= r || hipExtStreamCreateWithCUMask(&h->ustreams[r], (uint32_t)words, mask) != hipSuccess) {
             (void)hipGetLastError();
             RFLU_HIP(hipStreamCreateWithFlags(&h->ustreams[r], hipStreamNonBlocking));
         }
@@ -526,7 +529,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     if (blocksize < 0 || blocksize >= mn) {
         h->last_path = RFLU_PATH_HIP_RECURSIVE;
         RFLU_TRY(f.rec(0, mn));
-    } else if (!h->prof) {
+    } else if (!h->prof && h->num_cus == 256) {   // the CU reservation of the two-stream schedule is laid out for 8 x 32 CUs
         h->last_path = RFLU_PATH_HIP_LOOKAHEAD;
         RFLU_TRY(factor_lookahead<T>(f, round_up(blocksize, NB)));
         fat_tail_done = true;  // the block-column updates already reached the columns right of the square part
@@ -615,14 +618,35 @@ using namespace rflu;
 static Handle* H(rflu_handle_t h) { return reinterpret_cast<Handle*>(h); }
 namespace rflu { int get_ustream(Handle* h, int reserve, hipStream_t* out); }
 
-#define CHECK_HANDLE(h)                        \
-    do {                                       \
-        if ((h) == nullptr) {                  \
-            set_error("null handle");          \
-            return RFLU_ERR_ARG;               \
-        }                                      \
-        RFLU_HIP(hipSetDevice(H(h)->device));  \
-    } while (0)
+// Every API entry runs on the handle's device and leaves the caller's current device as it found it (a framework with
+// tensors on several GPUs must not find its current device changed by a library call).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+#define CHECK_HANDLE(h)                                  \
+    if ((h) == nullptr) {                                \
+        set_error("null handle");                        \
+        return RFLU_ERR_ARG;                             \
+    }                                                    \
+    DeviceGuard device_guard__(H(h)->device);            \
+    RFLU_HIP(device_guard__.err)
 
 extern "C" {
 
@@ -640,7 +664,8 @@ int rflu_create(rflu_handle_t* handle, int device)
         return RFLU_ERR_NODEVICE;
     }
     if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return RFLU_ERR_ARG; }
-    RFLU_HIP(hipSetDevice(device));
+    DeviceGuard device_guard__(device);
+    RFLU_HIP(device_guard__.err);
     hipDeviceProp_t prop;
     RFLU_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -669,7 +694,13 @@ int rflu_create(rflu_handle_t* handle, int device)
     RFLU_HIP(hipMemset(h->pscratch, 0, h->pscratch_bytes));
     RFLU_HIP(hipEventCreate(&h->ev0));
     RFLU_HIP(hipEventCreate(&h->ev1));
+    // the cooperative kernels spin on peer workgroups: all of a launch's workgroups must be resident at once.  Ask the
+    // runtime how many fit (one 512/576-thread workgroup per CU with these register counts) instead of assuming it.
+    h->panel_max_wgs = panel_resident_limit(h->num_cus);
+    if (h->panel_max_wgs <= 0) { set_error("occupancy query for the cooperative panel kernels failed"); delete h; return RFLU_ERR_HIP; }
+    if (const char* e = getenv("RFLU_COOP_LAUNCH")) h->coop_launch = atoi(e) != 0;
     if (const char* e = getenv("RFLU_PANEL_LOCAL")) h->panel_local = atoi(e);
+    if (h->panel_local == 1) h->panel_local_maxg = 32;   // one XCD has 32 CUs
     if (const char* e = getenv("RFLU_PANEL_LOCAL_MAXG")) h->panel_local_maxg = atoi(e);
     *handle = reinterpret_cast<rflu_handle_t>(h);
     return RFLU_OK;
@@ -679,7 +710,7 @@ int rflu_destroy(rflu_handle_t handle)
 {
     if (!handle) return RFLU_OK;
     Handle* h = H(handle);
-    (void)hipSetDevice(h->device);
+    DeviceGuard device_guard__(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->work) (void)hipFree(h->work);
     if (h->ipiv_dev) (void)hipFree(h->ipiv_dev);

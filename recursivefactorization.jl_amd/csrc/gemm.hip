@@ -336,7 +336,7 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
         }
     }
     const size_t lds = 2 * (size_t)G_STAGE * sizeof(T);
-    static bool attr_set = false;
+    bool& attr_set = h->gemm_attr_set[sizeof(T) == 8 ? 0 : 1];   // per handle = per device (not a process-wide static)
     if (!attr_set) {
         RFLU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sub_kernel<T, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

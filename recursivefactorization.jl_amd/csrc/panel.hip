@@ -24,6 +24,8 @@
 //
 // Roofline: neither HBM nor MFMA -- the bound is w x (one cross-CU hop, ~1-2 us).  Algorithmic work reported to the
 // timers: m*w^2 flops.
+#include <algorithm>
+
 #include "panel_common.hpp"
 
 namespace rflu {
@@ -884,7 +886,7 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
     int rt = 1;
     while ((rows + (int64_t)PANEL_THREADS * rt - 1) / ((int64_t)PANEL_THREADS * rt) > MAX_PANEL_WGS) rt *= 2;
     if (rt > 1) {
-        set_error("launch_panel: %lld rows exceed the supported 65536", (long long)rows);
+        set_error("launch_panel: %lld rows exceed the supported %d", (long long)rows, MAX_PANEL_WGS * PANEL_THREADS);
         return RFLU_ERR_ARG;
     }
     PanelArgs<T> p;
@@ -892,6 +894,10 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
     p.ipiv = ipiv; p.info = h->info_dev; p.scratch = h->pscratch;
     p.G = (int)((rows + (int64_t)PANEL_THREADS * rt - 1) / ((int64_t)PANEL_THREADS * rt));
     p.pm_cnt = h->pm_cnt; p.pm_dst = h->pm_dst; p.pm_src = h->pm_src;
+    if (pivot && p.G > 1 && p.G > h->panel_max_wgs) {   // the workgroups spin on each other: all must be resident at once
+        set_error("launch_panel: %d cooperating workgroups, but the device holds %d at a time", p.G, h->panel_max_wgs);
+        return RFLU_ERR_ARG;
+    }
     p.epoch = h->epoch;
     h->epoch += (unsigned)NB;
     if (h->epoch > 0xfffff000u) {  // tag wrap: wipe the records and restart the epoch counter
@@ -905,14 +911,20 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
         // 2..64 workgroups: the pipelined kernel, in which every wave polls one header per lane (RFLU_PIPE=0 selects the
         // two-trip kernel above, which also serves taller panels: measured 0.5 % faster there)
         static const bool pipe = [] { const char* e = getenv("RFLU_PIPE"); return e == nullptr || e[0] != '0'; }();
-        // XCD-local leaf (panel_local.hip): all workgroups on one XCD, records through that XCD's L2
-        if (h->panel_local > 0 && p.G >= 2 && p.G <= h->panel_local_maxg) {
+        // pipelined leaf with a communication wave (panel_local.hip); one header per lane of that wave: at most 64 workgroups
+        if (h->panel_local > 0 && p.G >= 2 && p.G <= std::min(h->panel_local_maxg, 64)) {
             RFLU_TRY(launch_panel_local<T>(h, p, h->panel_local == 1 ? 8 : 1, h->panel_local == 1 ? h->panel_xcc : 0,
                                            h->panel_local == 1 ? h->panel_xcc : -1, h->panel_local == 1));
             return RFLU_OK;
         }
-        if (pipe && p.G >= 2 && p.G <= 64) hipLaunchKernelGGL((panel_pivot_pipe_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
-        else hipLaunchKernelGGL((panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
+        void* kargs[] = {&p};
+        if (pipe && p.G >= 2 && p.G <= 64) {
+            if (h->coop_launch) RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_pipe_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), kargs, 0, h->stream));
+            else hipLaunchKernelGGL((panel_pivot_pipe_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
+        } else {
+            if (h->coop_launch && p.G > 1) RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), kargs, 0, h->stream));
+            else hipLaunchKernelGGL((panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
+        }
     } else {
         hipLaunchKernelGGL((panel_nopivot_top_kernel<T>), dim3(1), dim3(PANEL_THREADS), 0, h->stream, p);
         const int64_t below = rows - w;
@@ -950,14 +962,36 @@ int launch_panel_pair(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }
+// resident workgroups of this translation unit's cooperative kernels on a device with num_cus CUs (0: query failed)
+template <typename T>
+static int panel_resident_limit_t(int num_cus)
+{
+    int worst = 1 << 30;
+    auto ask = [&](const void* fn) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, PANEL_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        worst = std::min(worst, nb * num_cus);
+    };
+    ask(reinterpret_cast<const void*>(&panel_pivot_kernel<T, 1>));
+    ask(reinterpret_cast<const void*>(&panel_pivot_pipe_kernel<T>));
+    return worst;
+}
 // Two translation units compile this file in parallel (build.py): panel.hip itself instantiates the Float64 kernels and
 // holds the non-template functions, panel_f32.hip (#define RFLU_PANEL_F32_TU, #include "panel.hip") the Float32 kernels.
 #ifdef RFLU_PANEL_F32_TU
 template int launch_panel_pair<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t*);
 template int launch_panel<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
+int panel_resident_limit_f32(int num_cus) { return panel_resident_limit_t<float>(num_cus); }
 #else
+int panel_resident_limit_f64(int num_cus) { return panel_resident_limit_t<double>(num_cus); }
 template int launch_panel_pair<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t*);
 template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
+
+int panel_resident_limit(int num_cus)
+{
+    return std::min(std::min(panel_resident_limit_f64(num_cus), panel_resident_limit_f32(num_cus)),
+                    std::min(panel_local_resident_limit_f64(num_cus), panel_local_resident_limit_f32(num_cus)));
+}
 
 size_t panel_scratch_bytes() { return (PX_OFFSET_WORDS + PX_BYTES / 8 + RFLU_TRACE_ALL_WORDS) * sizeof(u64); }  // records | trace stamps | pair slots | all-workgroup trace
 size_t panel_trace_all_offset_bytes() { return (PX_OFFSET_WORDS + PX_BYTES / 8) * sizeof(u64); }

@@ -507,4 +507,9 @@ __device__ __forceinline__ void barrier_lds_only()
 template <typename T>
 int launch_panel_local(Handle* h, const PanelArgs<T>& p, int stride, int sel, int want_xcc, int local);
 
+int panel_resident_limit_f64(int num_cus);
+int panel_resident_limit_f32(int num_cus);
+int panel_local_resident_limit_f64(int num_cus);
+int panel_local_resident_limit_f32(int num_cus);
+
 }  // namespace rflu

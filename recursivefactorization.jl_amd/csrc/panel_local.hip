@@ -19,6 +19,8 @@
 // With LOCAL = false the same kernel runs with sc1 stores on any placement (stride 1).
 //
 // Roofline: latency -- w x (one L2 hop + two workgroup barriers + one division); work reported to the timers: m*w^2 flops.
+#include <algorithm>
+
 #include "panel_common.hpp"
 
 namespace rflu {
@@ -547,16 +549,38 @@ int launch_panel_local(Handle* h, const PanelArgs<T>& p, int stride, int sel, in
     la.sel = sel;
     la.want_xcc = want_xcc;
     const dim3 grid((unsigned)(p.G * stride));
+    if (h->coop_launch && stride == 1) {   // launch-time residency check by the runtime (opt-in: +15-19 us per launch)
+        void* kargs[] = {&la};
+        RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false>), grid,
+                                            dim3(PANEL_THREADS + 64), kargs, 0, h->stream));
+        return RFLU_OK;
+    }
     if (local) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true>), grid, dim3(PANEL_THREADS + 64), 0, h->stream, la);
     else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false>), grid, dim3(PANEL_THREADS + 64), 0, h->stream, la);
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }
 
+template <typename T>
+static int panel_local_resident_limit_t(int num_cus)
+{
+    int worst = 1 << 30;
+    auto ask = [&](const void* fn) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, PANEL_THREADS + 64, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        worst = std::min(worst, nb * num_cus);
+    };
+    ask(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, true>));
+    ask(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false>));
+    return worst;
+}
+
 #ifdef RFLU_PANEL_F32_TU
 template int launch_panel_local<float>(Handle*, const PanelArgs<float>&, int, int, int, int);
+int panel_local_resident_limit_f32(int num_cus) { return panel_local_resident_limit_t<float>(num_cus); }
 #else
 template int launch_panel_local<double>(Handle*, const PanelArgs<double>&, int, int, int, int);
+int panel_local_resident_limit_f64(int num_cus) { return panel_local_resident_limit_t<double>(num_cus); }
 #endif
 
 }  // namespace rflu

@@ -83,11 +83,16 @@ struct Handle {
     size_t pscratch_bytes = 0;
     unsigned epoch = 1;          // next unused granule tag
     int64_t* info_dev = nullptr; // [0] = info, [1] = panel error flags (bit0 timeout, bit1 XCD placement mismatch)
-    // XCD-local leaf kernel (panel_local.hip): 0 = off, 1 = on (participants = blocks b % 8 == panel_xcc of an 8*G grid,
-    // plain-store records), 2 = the same kernel with sc1 records on any placement
-    int panel_local = 0;
-    int panel_local_maxg = 32;
+    // pipelined leaf kernel with a communication wave (panel_local.hip), RFLU_PANEL_LOCAL: 0 = off (the kernels of
+    // panel.hip), 2 = on with sc1 records on any placement (default), 1 = all workgroups on XCD panel_xcc with plain-store
+    // records through that XCD's L2 (needs that XCD free: experiments only)
+    int panel_local = 2;
+    int panel_local_maxg = 64;
     int panel_xcc = 0;
+    int trsv_max_wgs = 0;        // same for the cooperative solve kernels (asked on first use)
+    int panel_max_wgs = 0;       // how many workgroups of the cooperative panel kernels the device holds at once (occupancy query)
+    bool coop_launch = false;    // RFLU_COOP_LAUNCH=1: hipLaunchCooperativeKernel (launch-time residency check, +15-19 us each)
+    bool gemm_attr_set[2] = {false, false};   // dynamic-LDS opt-in of the GEMM kernels done on this handle's device (f64, f32)
     int64_t* info_pinned = nullptr;
 
     // timers
@@ -151,6 +156,7 @@ int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64
 // fold the interchanges ipiv[k0..k1) (k0 a multiple of NB) into per-chunk row-move lists
 int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, int64_t m);
 size_t panel_scratch_bytes();
+int panel_resident_limit(int num_cus);   // min over the cooperative leaf kernels of (resident workgroups per CU) * num_cus
 size_t panel_trace_offset_bytes();
 size_t panel_trace_all_offset_bytes();
 size_t panel_trace_all_words();

@@ -295,6 +295,21 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
         return RFLU_ERR_ARG;
     }
     const unsigned grid = (unsigned)std::min<int64_t>(nb, TV_MAX_WGS);
+    {   // the stages wait for each other's results: every workgroup of a launch must be resident (asked once per handle)
+        if (h->trsv_max_wgs == 0) {
+            int a = 0, b = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&trsv_coop_kernel<T, false>), TV_THREADS, 0) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&trsv_coop_kernel<T, true>), TV_THREADS, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                a = b = 0;
+            }
+            h->trsv_max_wgs = std::max(1, std::min(a, b) * h->num_cus);
+        }
+        if ((int)grid > h->trsv_max_wgs) {
+            set_error("launch_trsv_coop: %u cooperating workgroups, but the device holds %d at a time", grid, h->trsv_max_wgs);
+            return RFLU_ERR_ARG;
+        }
+    }
     for (int64_t c0 = 0; c0 < nrhs; c0 += TV_NR) {
         const int nr = (int)std::min<int64_t>(TV_NR, nrhs - c0);
         ProfScope ps(h, RFLU_K_TRSM, 2.0 * (double)n * (double)n * (double)nr, sizeof(T) * (double)n * (double)n);

@@ -16,9 +16,9 @@ Same names, argument meaning and error behaviour; Julia's ``!`` is spelled ``_``
     recursive/unblocked crossover, :90,114) is accepted and ignored, and there is NO CPU fallback: other element types
     raise ``TypeError`` (the Julia glue in INTEGRATION.md keeps the reference's own CPU code for those);
   * ``thread`` is accepted and ignored (the GPU path has no thread flag);
-  * ``blocksize``: ``None``/0 = library default (pure Toledo recursion below 4096 columns, 1024-wide block columns with
-    one block column of lookahead above); negative = pure recursion; 64/128/256... = width of the outer right-looking
-    block column (include/rflu.h).
+  * ``blocksize``: ``None``/0 = library default (pure Toledo recursion below 1024 columns; above, right-looking block
+    columns of 128 ... 2048 by matrix size with one block column of lookahead, see include/rflu.h); negative = pure
+    recursion; 64/128/256... = width of the outer right-looking block column.
 
 Inputs: a NumPy array (host; staged through HBM by ``rflu_getrf_*``) or a ``torch`` tensor on the GPU
 (column-major view, i.e. ``stride(0) == 1``, -> ``rflu_getrf_*_dev``; C-contiguous -> ``rflu_getrf_rm_*_dev``).
@@ -282,6 +282,9 @@ def ldiv_(F: LU, B, *, handle=None):
         h = handle or _ffi.default_handle(A.device.index or 0)
         h.set_stream(torch.cuda.current_stream(A.device).cuda_stream)
         ip = ctypes.c_void_p(0 if nopiv else F.ipiv.data_ptr())
+        if B.ndim == 1 and n > 1 and B.stride(0) != 1:
+            # a strided vector view (e.g. a column of a row-major tensor) would be read and written at the wrong addresses
+            raise ValueError("a vector right-hand side must be contiguous (stride 1); copy the view first")
         if A.stride(0) == 1:  # column-major factors -> column-major right-hand sides
             if B.ndim == 2 and not (B.stride(0) == 1 and B.stride(1) >= n):
                 raise ValueError("B must be column-major like the factors")
@@ -289,8 +292,8 @@ def ldiv_(F: LU, B, *, handle=None):
             h.call(f"rflu_getrs_{sfx}_dev", n, nrhs, ctypes.c_void_p(A.data_ptr()), A.stride(1), ip,
                    ctypes.c_void_p(B.data_ptr()), ldb)
         else:                 # row-major factors (rflu_getrf_rm) -> row-major right-hand sides
-            if B.ndim == 2 and B.stride(1) != 1:
-                raise ValueError("B must be row-major like the factors")
+            if B.ndim == 2 and not (B.stride(1) == 1 and B.stride(0) >= nrhs):
+                raise ValueError("B must be row-major like the factors (unit column stride, row stride >= nrhs)")
             ldb = 1 if B.ndim == 1 else B.stride(0)
             h.call(f"rflu_getrs_rm_{sfx}_dev", n, nrhs, ctypes.c_void_p(A.data_ptr()), A.stride(0), ip,
                    ctypes.c_void_p(B.data_ptr()), ldb)

@@ -81,6 +81,34 @@ def test_lu_nopivot(dtype, s):
     assert np.linalg.norm(A.astype(np.float64) @ x - b) < 1000 * n * np.finfo(dtype).eps
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("pivot", [True, False])
+@pytest.mark.parametrize("s", [3, 10, 50, 130, 300])
+def test_lu_adjoint_transpose_wrappers(dtype, pivot, s):
+    # test/runtests.jl:55-58: A' = permutedims(A); MF' = lu(A'' ...) -- the wrapper forwards to the parent and wraps the
+    # result (src/lu.jl:85-87); testlu then looks at parent(MF') against parent(A'') = A' (tall when A is fat)
+    for m in (s, s + 2):
+        A = rand_matrix(s, m, seed=4000 * s + m, dtype=dtype)
+        if not pivot:
+            A = (A + dtype(10) * np.eye(s, m, dtype=dtype)).astype(dtype, order="F")
+        At = np.asfortranarray(A.T.copy())           # permutedims(A): an m x s matrix in its own storage
+        for wrap in (rf.Adjoint, rf.Transpose):
+            MF = rf.lu(wrap(At), rf.Val(pivot), check=False)
+            assert isinstance(MF, rf.Adjoint)
+            P = MF.parent                            # LU of A' itself
+            if pivot:
+                check_against_oracle(At, P)
+            else:
+                assert isinstance(P.ipiv, rf.NotIPIV)
+                check_against_oracle(At, rf.LU(P.factors, np.arange(1, min(At.shape) + 1), P.info), pivot=False)
+        # in-place form on a device matrix: lu!(A'') factors the parent's storage
+        dAt = to_dev_cm(At)
+        MF = rf.lu_(rf.Adjoint(dAt), None, pivot, check=False)
+        assert MF.parent.factors is dAt
+        if pivot:
+            check_against_oracle(At, MF.parent)
+
+
 def test_nopivot_zero_pivot_sign_convention():
     A = np.asfortranarray(np.triu(rand_matrix(100, 100, seed=6)) + 10 * np.eye(100))
     A[70, 70] = 0.0

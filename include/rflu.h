@@ -159,8 +159,13 @@ int rflu_fill_uniform_f64_dev(rflu_handle_t handle, double* A_dev, int64_t m, in
                               uint64_t seed, int64_t M_global, int64_t i0, int64_t j0, double diag_add);
 int rflu_fill_uniform_f32_dev(rflu_handle_t handle, float* A_dev, int64_t m, int64_t n, int64_t ld, int row_major,
                               uint64_t seed, int64_t M_global, int64_t i0, int64_t j0, double diag_add);
-/* ---- built-in per-kernel timers (hipEvents on the handle's stream around every launch of a class) ----
- * enable != 0 starts collecting (and resets); rflu_profile_get returns accumulated milliseconds, launch count and the
+/* ---- built-in per-kernel timers (hipEvents on the launch stream around every launch of a class) ----
+ * enable = 1: synchronous mode -- every launch is bracketed and waited for; the factorization then runs the one-stream
+ *             blocked schedule (each kernel alone on the GPU: the kernel's own roofline);
+ * enable = 2: in-schedule mode -- event pairs are recorded on whatever stream a launch goes to and resolved when the
+ *             timers are read; the default two-stream lookahead schedule is left untouched (what a kernel achieves next
+ *             to the other stream's work);
+ * enable = 0: off.  Enabling resets the timers.  rflu_profile_get returns accumulated milliseconds, launch count and the
  * algorithmic work (flops for GEMM/TRSM/PANEL, bytes for LASWP/TRANSPOSE) of class k since enabling. */
 int rflu_profile_enable(rflu_handle_t handle, int enable);
 int rflu_profile_get(rflu_handle_t handle, int kclass, double* ms, int64_t* launches, double* work);

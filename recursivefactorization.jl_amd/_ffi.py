@@ -133,8 +133,9 @@ class Handle:
         check(self.lib.rflu_update_stream(self.ptr, ctypes.byref(out)))
         return int(out.value)
 
-    def profile_enable(self, on: bool):
-        check(self.lib.rflu_profile_enable(self.ptr, int(bool(on))))
+    def profile_enable(self, on):
+        """False/0 = off, True/1 = synchronous per-launch timers (one-stream schedule), 2 = in-schedule event pairs."""
+        check(self.lib.rflu_profile_enable(self.ptr, int(on)))
 
     def profile(self) -> dict:
         out = {}

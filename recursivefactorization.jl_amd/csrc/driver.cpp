@@ -730,6 +730,8 @@ int rflu_destroy(rflu_handle_t handle)
     for (hipStream_t us : h->ustreams)
         if (us) (void)hipStreamDestroy(us);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    for (auto& r : h->async_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : h->async_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return RFLU_OK;
@@ -901,8 +903,29 @@ int rflu_profile_enable(rflu_handle_t handle, int enable)
 {
     CHECK_HANDLE(handle);
     Handle* h = H(handle);
-    h->prof = enable != 0;
+    h->prof = enable == 1;
+    h->prof_async = enable == 2;
     for (int k = 0; k < RFLU_K_COUNT; ++k) h->slots[k] = ProfSlot();
+    for (auto& r : h->async_recs) { h->async_pool.push_back(r.a); h->async_pool.push_back(r.b); }
+    h->async_recs.clear();
+    return RFLU_OK;
+}
+
+// in-schedule mode: fold the pending event pairs into the per-class timers (waits for the recorded work)
+static int profile_resolve(Handle* h)
+{
+    for (auto& r : h->async_recs) {
+        RFLU_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        RFLU_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        h->slots[r.k].ms += ms;
+        h->slots[r.k].launches += 1;
+        h->slots[r.k].work += r.work;
+        h->slots[r.k].bytes += r.bytes;
+        h->async_pool.push_back(r.a);
+        h->async_pool.push_back(r.b);
+    }
+    h->async_recs.clear();
     return RFLU_OK;
 }
 
@@ -910,6 +933,7 @@ int rflu_profile_get(rflu_handle_t handle, int kclass, double* ms, int64_t* laun
 {
     CHECK_HANDLE(handle);
     if (kclass < 0 || kclass >= RFLU_K_COUNT) { set_error("bad kernel class %d", kclass); return RFLU_ERR_ARG; }
+    RFLU_TRY(profile_resolve(H(handle)));
     const ProfSlot& s = H(handle)->slots[kclass];
     if (ms) *ms = s.ms;
     if (launches) *launches = s.launches;
@@ -921,6 +945,7 @@ int rflu_profile_get_bytes(rflu_handle_t handle, int kclass, double* bytes)
 {
     CHECK_HANDLE(handle);
     if (kclass < 0 || kclass >= RFLU_K_COUNT || bytes == nullptr) { set_error("bad kernel class %d", kclass); return RFLU_ERR_ARG; }
+    RFLU_TRY(profile_resolve(H(handle)));
     *bytes = H(handle)->slots[kclass].bytes;
     return RFLU_OK;
 }

@@ -96,9 +96,13 @@ struct Handle {
     int64_t* info_pinned = nullptr;
 
     // timers
-    bool prof = false;
+    bool prof = false;           // synchronous mode: every launch bracketed and waited for (switches to the one-stream schedule)
+    bool prof_async = false;     // in-schedule mode: event pairs recorded on the launch streams, resolved by profile_get
     ProfSlot slots[RFLU_K_COUNT];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct AsyncRec { int k; hipEvent_t a, b; double work, bytes; };
+    std::vector<AsyncRec> async_recs;      // pending event pairs of the in-schedule mode
+    std::vector<hipEvent_t> async_pool;    // timing events kept for reuse
 };
 
 struct ProfScope {
@@ -107,10 +111,26 @@ struct ProfScope {
     double work;
     double bytes;
     bool on;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    static hipEvent_t take(Handle* h) {
+        if (!h->async_pool.empty()) { hipEvent_t e = h->async_pool.back(); h->async_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
     ProfScope(Handle* h_, int k_, double work_, double bytes_ = 0.0) : h(h_), k(k_), work(work_), bytes(bytes_), on(h_->prof) {
         if (on) (void)hipEventRecord(h->ev0, h->stream);
+        else if (h->prof_async) {   // no wait: the pair is resolved when the timers are read
+            ea = take(h);
+            eb = take(h);
+            if (ea) (void)hipEventRecord(ea, h->stream);
+        }
     }
     ~ProfScope() {
+        if (ea && eb) {
+            (void)hipEventRecord(eb, h->stream);
+            h->async_recs.push_back({k, ea, eb, work, bytes});
+        }
         if (on) {
             (void)hipEventRecord(h->ev1, h->stream);
             (void)hipEventSynchronize(h->ev1);

@@ -95,6 +95,61 @@ def cpu_baseline(cpu_n: int):
     return res, ipiv
 
 
+def mgpu_matvec_residual(mg, n, slabs, lds, layout, block, run, pivot, trials=2):
+    """max over random x of ||P*A*x - L*(U*x)|| / ||A*x|| for factors held in block-column slabs (one per device), A
+    regenerated from the seed into scratch slabs; O(n^2) per device, plain torch ops as an independent checker."""
+    import numpy as np
+    import torch
+
+    ipiv, _ = None, None
+    dev0 = slabs[0].device
+    As, _, _ = mg.alloc(n, slabs[0].dtype, block, run)
+    mg.fill_uniform(n, As, lds, block, run, seed=SEED)
+    # the pivots live on the host after getrf: factor() returned them; recompute the permutation from the last call
+    ipiv = mg.last_ipiv
+    perm = np.arange(n)
+    if pivot:
+        for i, t in enumerate(ipiv):
+            j = int(t) - 1
+            if j != i:
+                perm[i], perm[j] = perm[j], perm[i]
+    perm = torch.from_numpy(perm).to(dev0)
+    cols = []
+    for d in range(mg.ndev):
+        cs = [torch.arange(j0, j0 + w) for (j0, w, o, lc) in layout if o == d]
+        cols.append(torch.cat(cs).to(slabs[d].device) if cs else torch.zeros(0, dtype=torch.int64, device=slabs[d].device))
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    worst = 0.0
+    for _ in range(trials):
+        x = torch.rand(n, dtype=torch.float64, generator=gen)
+        ax = torch.zeros(n, dtype=torch.float64, device=dev0)
+        ux = torch.zeros(n, dtype=torch.float64, device=dev0)
+        for d in range(mg.ndev):
+            nl = cols[d].numel()
+            if nl == 0:
+                continue
+            dd = slabs[d].device
+            xl = x.to(dd)[cols[d]]
+            rows = torch.arange(n, device=dd)[:, None]
+            ax += (As[d][:, :nl].to(torch.float64) @ xl).to(dev0)
+            LUd = slabs[d][:, :nl].to(torch.float64)
+            ux += (torch.where(rows <= cols[d][None, :], LUd, torch.zeros((), dtype=torch.float64, device=dd)) @ xl).to(dev0)
+            del LUd
+        lz = ux.clone()
+        for d in range(mg.ndev):
+            nl = cols[d].numel()
+            if nl == 0:
+                continue
+            dd = slabs[d].device
+            rows = torch.arange(n, device=dd)[:, None]
+            LUd = slabs[d][:, :nl].to(torch.float64)
+            lz += (torch.where(rows > cols[d][None, :], LUd, torch.zeros((), dtype=torch.float64, device=dd)) @ ux.to(dd)[cols[d]]).to(dev0)
+            del LUd
+        r = torch.linalg.norm(ax[perm] - lz) / torch.linalg.norm(ax)
+        worst = max(worst, float(r.item()))
+    return worst
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -161,12 +216,47 @@ def main():
         from recursivefactorization.jl_amd import distributed as D
 
         # runs of 4 consecutive block columns per owner: 3 of 4 panel broadcasts overlap with the owner's next panel instead
-        # of sitting on the critical chain (distributed.py); RFLU_DIST_RUN overrides
+        # of sitting on the critical chain; RFLU_DIST_RUN overrides
         run = int(os.environ.get("RFLU_DIST_RUN", "4" if world > 1 else "1"))
-        job = D.BlockColumnLU(D.HipOps(h, sfx), n, tdt, rank, world, dev, block=args.block, pivot=bool(pivot), seed=SEED,
-                              always_broadcast=force_dist, run=run)
-        regenerate = job.regenerate
-        step = job.factor
+        # Default at N > 1: the multi-GPU C entry of librflu.so (rflu_getrf_*_mgpu): ONE process -- rank 0 -- drives all N
+        # GPUs, ncclBroadcast of {panel, pivots} on the library's own streams, no host synchronisation per block column;
+        # the other ranks only take part in the barriers.  RFLU_BENCH_MGPU=python (or a failure to set the C path up)
+        # selects the one-process-per-GPU torch.distributed driver (recursivefactorization.jl_amd/distributed.py).
+        mgpu_mode = os.environ.get("RFLU_BENCH_MGPU", "c" if (world > 1 and not one_gpu) else "python")
+        mg = None
+        if mgpu_mode == "c":
+            ok = torch.zeros(1, dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+            if rank == 0:
+                try:
+                    from recursivefactorization.jl_amd.multigpu import MultiGPU
+
+                    # RFLU_BENCH_ONE_GPU rehearsal: the N logical devices all name GPU 0 ("fake multi-GPU": copies instead of
+                    # the RCCL broadcast) -- functional only, never a performance number
+                    mg = MultiGPU([0] * world if one_gpu else list(range(world)))
+                    slabs, lds, mlayout = mg.alloc(n, tdt, args.block, run)
+                    ok[0] = 1
+                except Exception as exc:  # noqa: BLE001 -- reported, then the python driver takes over
+                    print(f"bench: multi-GPU C entry unavailable ({exc}); using the torch.distributed driver", file=sys.stderr)
+                    mg = None
+            dist.broadcast(ok, src=0)
+            if int(ok.item()) != 1:
+                mgpu_mode = "python"
+        if mgpu_mode == "c":
+            mg_info = [0]
+
+            def regenerate():
+                if rank == 0:
+                    mg.fill_uniform(n, slabs, lds, args.block, run, seed=SEED)
+
+            def step():
+                if rank == 0:
+                    _, mg_info[0] = mg.getrf(n, slabs, lds, args.block, run, pivot=bool(pivot))
+            job = None
+        else:
+            job = D.BlockColumnLU(D.HipOps(h, sfx), n, tdt, rank, world, dev, block=args.block, pivot=bool(pivot), seed=SEED,
+                                  always_broadcast=force_dist, run=run)
+            regenerate = job.regenerate
+            step = job.factor
 
     for _ in range(args.warmup):
         regenerate()
@@ -196,8 +286,19 @@ def main():
         h.profile_enable(True)
         if single:
             step()
-        else:
+        elif job is not None:
             job.factor_sync()   # one block column at a time on one stream: every launch bracketed by HIP events
+        elif rank == 0:
+            # C entry: the per-GPU kernels are those of the single-GPU path; profile one single-GPU factorization of the
+            # 1-GPU workload size on device 0 (the multi-GPU handles keep no per-class timers)
+            np1 = min(n, DEFAULT_N[1])
+            Ap = torch.empty((np1, np1), dtype=tdt, device=dev)
+            ipp = torch.empty(np1, dtype=torch.int64, device=dev)
+            infp = ctypes.c_int64(0)
+            h.call(f"rflu_fill_uniform_{sfx}_dev", ctypes.c_void_p(Ap.data_ptr()), np1, np1, np1, 0, SEED, np1, 0, 0, 0.0)
+            h.call(f"rflu_getrf_{sfx}_dev", np1, np1, ctypes.c_void_p(Ap.data_ptr()), np1, ctypes.c_void_p(ipp.data_ptr()),
+                   pivot, 0, ctypes.byref(infp))
+            del Ap, ipp
         barrier()
         kern = h.profile()
         h.profile_enable(False)
@@ -220,7 +321,10 @@ def main():
                     "note": ("all gemm_sub_kernel launches of one profiled factorization (single-stream blocked schedule, HIP "
                              "events on the launch stream); traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 per launch from "
                              "profiles/*pmc*") if single else
-                            "rank 0's gemm_sub_kernel launches of one profiled single-stream factorization (per-GPU figure)"}
+                            ("rank 0's gemm_sub_kernel launches of one profiled single-stream factorization (per-GPU figure)"
+                             if job is not None else
+                             "per-GPU kernel: gemm_sub_kernel launches of one profiled single-GPU factorization of the 1-GPU "
+                             "workload on device 0 (the multi-GPU run uses the same kernel on every device)")}
 
     # ---- the same kernels inside the shipped two-stream schedule (event pairs on the launch streams, nothing waited for):
     # what the GEMM achieves next to the critical-path stream, and the HBM rate of the row interchanges (laswp)
@@ -302,8 +406,12 @@ def main():
         del L, U, R, PA
 
     if not args.no_check and not single:
-        check["residual_matvec"] = job.matvec_residual()
-        check["info"] = int(job.info)
+        if job is not None:
+            check["residual_matvec"] = job.matvec_residual()
+            check["info"] = int(job.info)
+        elif rank == 0:
+            check["residual_matvec"] = mgpu_matvec_residual(mg, n, slabs, lds, mlayout, args.block, run, pivot)
+            check["info"] = int(mg_info[0])
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and single:
@@ -331,7 +439,9 @@ def main():
                                    f"matrix, {'partial pivoting' if pivot else 'NoPivot'}, column-major in HBM",
                        "n": n, "pivot": bool(pivot), "blocksize": args.blocksize,
                        "layout": "single GPU" if world == 1 else
-                                 f"1-D block-column cyclic over {world} GPUs (block {args.block}, runs of {run})",
+                                 f"1-D block-column cyclic over {world} GPUs (block {args.block}, runs of {run}); " +
+                                 ("rflu_getrf_*_mgpu: one process drives all GPUs, ncclBroadcast on the library's streams"
+                                  if job is None else "one process per GPU, torch.distributed broadcast (RCCL)"),
                        "timing": "K steps in one bracket (barrier+sync both sides); a step = device refill of the input + lu!"},
             "frac_of_mfma_peak": round(gflops / 1e3 / (PEAK_TFLOPS[sfx] * args.gpus), 4),
             "roofline": roof,

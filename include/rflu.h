@@ -159,6 +159,33 @@ int rflu_fill_uniform_f64_dev(rflu_handle_t handle, double* A_dev, int64_t m, in
                               uint64_t seed, int64_t M_global, int64_t i0, int64_t j0, double diag_add);
 int rflu_fill_uniform_f32_dev(rflu_handle_t handle, float* A_dev, int64_t m, int64_t n, int64_t ld, int row_major,
                               uint64_t seed, int64_t M_global, int64_t i0, int64_t j0, double diag_add);
+/* ---- multi-GPU: 1-D block-column layout over the GPUs of one node, ONE process (BASELINE configs 3-4).
+ * The reference has no distributed path; this is the partition the north star specifies.  Block column b (width `block`, a
+ * multiple of 64) lives on logical device (b / run) % ndev inside that device's ROW-MAJOR slab (n rows x its local
+ * columns, element (i, jl) at slab[i*ld + jl]); per block column the owner factors the panel with the single-GPU
+ * recursion and ONE ncclBroadcast (RCCL, enqueued on the library's panel streams -- no host synchronisation per block
+ * column) carries {L\U panel, pivot segment} to the other devices, which then apply laswp / TRSM / GEMM to their slabs;
+ * one block column of lookahead.  devs[] may name ONE physical device several times ("fake multi-GPU"): the broadcast
+ * then is a device-to-device copy, so the whole partition logic runs -- and is tested -- on a single GPU.
+ * ipiv_host (length n, HOST memory, global 1-based rows) and *info as for rflu_getrf_*; ipiv_host may be NULL iff pivot == 0. */
+typedef struct rflu_mgpu_s* rflu_mgpu_t;
+int rflu_mgpu_create(rflu_mgpu_t* out, int ndev, const int* devs);
+int rflu_mgpu_destroy(rflu_mgpu_t mgpu);
+int rflu_mgpu_ndev(rflu_mgpu_t mgpu);
+int rflu_mgpu_is_fake(rflu_mgpu_t mgpu);
+/* number of local columns of logical device d for an n-column matrix (-1 on bad arguments) */
+int64_t rflu_mgpu_local_cols(int64_t n, int64_t block, int ndev, int64_t run, int d);
+int rflu_getrf_f64_mgpu(rflu_mgpu_t mgpu, int64_t n, double* const* slabs_dev, const int64_t* lds, int64_t* ipiv_host,
+                        int pivot, int64_t block, int64_t run, int64_t* info);
+int rflu_getrf_f32_mgpu(rflu_mgpu_t mgpu, int64_t n, float* const* slabs_dev, const int64_t* lds, int64_t* ipiv_host,
+                        int pivot, int64_t block, int64_t run, int64_t* info);
+/* synthetic input (bench / tests): every slab receives its block columns of the n x n uniform[0,1) matrix of
+ * rflu_fill_uniform_* (same seed -> the same matrix as on one GPU) */
+int rflu_mgpu_fill_uniform_f64(rflu_mgpu_t mgpu, int64_t n, double* const* slabs_dev, const int64_t* lds, int64_t block,
+                               int64_t run, uint64_t seed, double diag_add);
+int rflu_mgpu_fill_uniform_f32(rflu_mgpu_t mgpu, int64_t n, float* const* slabs_dev, const int64_t* lds, int64_t block,
+                               int64_t run, uint64_t seed, double diag_add);
+
 /* ---- built-in per-kernel timers (hipEvents on the launch stream around every launch of a class) ----
  * enable = 1: synchronous mode -- every launch is bracketed and waited for; the factorization then runs the one-stream
  *             blocked schedule (each kernel alone on the GPU: the kernel's own roofline);

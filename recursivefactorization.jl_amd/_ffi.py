@@ -47,6 +47,15 @@ _PLAIN = {
     "rflu_synchronize": (c_int, [c_p]),
     "rflu_last_path": (c_int, [c_p]),
     "rflu_update_stream": (c_int, [c_p, ctypes.POINTER(c_p)]),
+    "rflu_mgpu_create": (c_int, [ctypes.POINTER(c_p), c_int, ctypes.POINTER(c_int)]),
+    "rflu_mgpu_destroy": (c_int, [c_p]),
+    "rflu_mgpu_ndev": (c_int, [c_p]),
+    "rflu_mgpu_is_fake": (c_int, [c_p]),
+    "rflu_mgpu_local_cols": (c_i64, [c_i64, c_i64, c_int, c_i64, c_int]),
+    "rflu_getrf_f64_mgpu": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_int, c_i64, c_i64, c_p]),
+    "rflu_getrf_f32_mgpu": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_int, c_i64, c_i64, c_p]),
+    "rflu_mgpu_fill_uniform_f64": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_u64, c_dbl]),
+    "rflu_mgpu_fill_uniform_f32": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_u64, c_dbl]),
     "rflu_profile_enable": (c_int, [c_p, c_int]),
     "rflu_profile_get": (c_int, [c_p, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl)]),
     "rflu_profile_get_bytes": (c_int, [c_p, c_int, ctypes.POINTER(c_dbl)]),

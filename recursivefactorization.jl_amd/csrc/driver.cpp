@@ -899,6 +899,469 @@ int rflu_debug_panel_trace_all(rflu_handle_t handle, long long* out, long long m
     return (int)nw;
 }
 
+}  // extern "C" (the multi-GPU internals below are C++)
+
+/* =====================================================================================================================
+ * Multi-GPU: 1-D block-column layout over the GPUs of one node (BASELINE configs 3-4), ONE process.
+ * The reference has no distributed path; this is the partition the north star asks for:
+ *   - block column b (width `block`, a multiple of 64) lives on logical device (b / run) % ndev as part of that device's
+ *     row-major slab (all n rows x its local columns); `run` consecutive block columns share an owner;
+ *   - per block column the owner factors the tall panel with the single-GPU recursion (the same Fact::rec as
+ *     rflu_panel_rm_*), packs {L\U panel rows j0.. | ipiv segment} and ONE broadcast carries it to the other devices --
+ *     ncclBroadcast (RCCL over xGMI) enqueued on the library's own panel streams, no host synchronisation anywhere in the
+ *     loop; every device then applies laswp -> TRSM -> GEMM to its local columns;
+ *   - one block column of lookahead: the owner of b+1 updates that slice first and factors it on its panel stream while
+ *     all devices still run the bulk of update b on their (CU-masked) update streams.
+ * "Fake multi-GPU" (SURVEY.md 4(iii)): the same logical device list may name ONE physical device several times; the
+ * broadcast then is a device-to-device copy and the whole partition / message / ordering logic runs on a single GPU --
+ * what the -m gpu tests exercise with k = 2, 4, 8.
+ * ===================================================================================================================== */
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace rflu {
+
+struct Rccl {   // resolved lazily: single-GPU users of librflu.so never load RCCL
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    int load()
+    {
+        if (lib) return RFLU_OK;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { set_error("cannot load RCCL (librccl.so): %s", dlerror()); return RFLU_ERR_HIP; }
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !Broadcast || !GroupStart || !GroupEnd || !GetErrorString) {
+            set_error("librccl.so lacks an expected symbol");
+            return RFLU_ERR_HIP;
+        }
+        return RFLU_OK;
+    }
+};
+
+#define RFLU_NCCL(r, call)                                                                          \
+    do {                                                                                            \
+        ncclResult_t e__ = (call);                                                                  \
+        if (e__ != ncclSuccess) {                                                                   \
+            set_error("%s failed: %s (%s:%d)", #call, (r).GetErrorString(e__), __FILE__, __LINE__); \
+            return RFLU_ERR_HIP;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+struct Mgpu {
+    int ndev = 0;
+    bool fake = false;                 // a physical device is named more than once: broadcast = device-to-device copy
+    std::vector<int> devs;
+    std::vector<Handle*> h;            // one handle (streams, workspaces, exchange scratch) per logical device
+    std::vector<ncclComm_t> comms;     // real multi-GPU only
+    Rccl rccl;
+    // per logical device: packed panel buffers (double-buffered by block-column parity), pivot vector, stream pair, events
+    std::vector<void*> pbuf[2];
+    std::vector<size_t> pbuf_bytes[2];
+    std::vector<int64_t*> meta[2];     // ipiv segment of the block column (wmax entries)
+    std::vector<size_t> meta_cap;
+    std::vector<int64_t*> ipiv;        // full pivot vector (n) on every device
+    std::vector<size_t> ipiv_cap;
+    std::vector<hipStream_t> U, P;
+    std::vector<std::vector<hipEvent_t>> ev;   // ev[d]: reusable, timing disabled
+};
+
+struct BlockCol { int64_t j0, w; int owner; int64_t lc; };
+
+static void mgpu_layout(int64_t n, int64_t block, int ndev, int64_t run, std::vector<BlockCol>& out, std::vector<int64_t>& local_cols)
+{
+    out.clear();
+    local_cols.assign(ndev, 0);
+    const int64_t nb = (n + block - 1) / block;
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t j0 = b * block, w = std::min(block, n - j0);
+        const int owner = (int)((b / std::max<int64_t>(run, 1)) % ndev);
+        out.push_back({j0, w, owner, local_cols[owner]});
+        local_cols[owner] += w;
+    }
+}
+
+static int mgpu_event(Mgpu* g, int d, size_t idx, hipEvent_t* out)
+{
+    auto& v = g->ev[d];
+    while (v.size() <= idx) {
+        hipEvent_t e;
+        RFLU_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        v.push_back(e);
+    }
+    *out = v[idx];
+    return RFLU_OK;
+}
+
+// apply block column (j0, w), held packed in pb (rows j0.. x w, leading dimension w), to local columns [c0, c0+ncols) of R
+template <typename T>
+static int mgpu_update(Handle* h, int64_t n, T* R, int64_t ld, const T* pb, int64_t j0, int64_t w, int64_t c0, int64_t ncols,
+                       int pivot)
+{
+    if (ncols <= 0) return RFLU_OK;
+    if (pivot) RFLU_TRY(launch_laswp<T>(h, R, ld, c0, ncols, j0 / NB, (j0 + w + NB - 1) / NB));
+    RFLU_TRY(trsm_public<T>(h, w, ncols, pb, w, R + j0 * ld + c0, ld));
+    if (n > j0 + w) RFLU_TRY(launch_gemm<T>(h, n - j0 - w, ncols, w, pb + w * w, w, R + j0 * ld + c0, ld, R + (j0 + w) * ld + c0, ld));
+    return RFLU_OK;
+}
+
+template <typename T>
+static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, int64_t* ipiv_host, int pivot, int64_t block,
+                      int64_t run, int64_t* info)
+{
+    if (n < 0 || slabs == nullptr || lds == nullptr || info == nullptr || block <= 0 || block % NB != 0 || run <= 0 ||
+        (pivot && ipiv_host == nullptr && n > 0)) {
+        set_error("mgpu getrf: bad arguments (block must be a positive multiple of %d)", NB);
+        return RFLU_ERR_ARG;
+    }
+    *info = 0;
+    if (n == 0) return RFLU_OK;
+    const int D = g->ndev;
+    std::vector<BlockCol> lay;
+    std::vector<int64_t> ncols_loc;
+    mgpu_layout(n, block, D, run, lay, ncols_loc);
+    const int64_t nb = (int64_t)lay.size();
+    const int64_t wmax = std::min(block, n);
+    DeviceGuard guard(g->devs[0]);
+    RFLU_HIP(guard.err);
+    for (int d = 0; d < D; ++d) {
+        if (lds[d] < std::max<int64_t>(ncols_loc[d], 1) || (ncols_loc[d] > 0 && slabs[d] == nullptr)) {
+            set_error("mgpu getrf: slab %d needs %lld columns (ld %lld)", d, (long long)ncols_loc[d], (long long)lds[d]);
+            return RFLU_ERR_ARG;
+        }
+        RFLU_HIP(hipSetDevice(g->devs[d]));
+        Handle* h = g->h[d];
+        RFLU_TRY(ensure_bookkeeping(h, n));
+        for (int par = 0; par < 2; ++par) {
+            RFLU_TRY(ensure_buffer(&g->pbuf[par][d], &g->pbuf_bytes[par][d], (size_t)n * (size_t)wmax * sizeof(T)));
+            if ((size_t)wmax > g->meta_cap[d]) {
+                if (g->meta[par][d]) RFLU_HIP(hipFree(g->meta[par][d]));
+                g->meta[par][d] = nullptr;
+                RFLU_HIP(hipMalloc((void**)&g->meta[par][d], (size_t)wmax * sizeof(int64_t)));
+            }
+        }
+        g->meta_cap[d] = std::max(g->meta_cap[d], (size_t)wmax);
+        if ((size_t)n > g->ipiv_cap[d]) {
+            if (g->ipiv[d]) RFLU_HIP(hipFree(g->ipiv[d]));
+            g->ipiv[d] = nullptr;
+            RFLU_HIP(hipMalloc((void**)&g->ipiv[d], (size_t)n * sizeof(int64_t)));
+            g->ipiv_cap[d] = (size_t)n;
+        }
+        if (!g->U[d]) RFLU_TRY(get_ustream(h, 32, &g->U[d]));
+        g->P[d] = h->own_stream;
+        h->last_path = RFLU_PATH_HIP_LOOKAHEAD;
+        // start state on both streams of the device
+        h->stream = g->U[d];
+        RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), g->U[d]));
+        if (!pivot) RFLU_TRY(launch_iota_ipiv(h, g->ipiv[d], 0, n));
+        hipEvent_t e0;
+        RFLU_TRY(mgpu_event(g, d, 0, &e0));
+        RFLU_HIP(hipEventRecord(e0, g->U[d]));
+        RFLU_HIP(hipStreamWaitEvent(g->P[d], e0, 0));
+    }
+    // events per device: 1 + 4*b + {0: packed/received, 1: slice ready, 2: update done}
+    auto EV = [&](int d, int64_t b, int k, hipEvent_t* e) { return mgpu_event(g, d, (size_t)(1 + 4 * b + k), e); };
+    const ncclDataType_t ntype = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+
+    // factor + pack block column b on its owner's panel stream, then carry it to every other device
+    auto produce = [&](int64_t b) -> int {
+        const BlockCol& c = lay[b];
+        const int o = c.owner;
+        const int par = (int)(b & 1);
+        const int64_t rows = n - c.j0;
+        hipEvent_t e;
+        for (int d = 0; d < D; ++d) {   // the parity buffer was last read by update b-2 on every device
+            if (b >= 2) {
+                RFLU_HIP(hipSetDevice(g->devs[d]));
+                RFLU_TRY(EV(d, b - 2, 2, &e));
+                RFLU_HIP(hipStreamWaitEvent(g->P[d], e, 0));
+                if (g->fake) {
+                    // without a collective the receivers of b-2 copied straight out of ITS owner's buffer, each at its own
+                    // pace: nobody may overwrite a parity buffer before every logical device has block column b-2
+                    for (int d2 = 0; d2 < D; ++d2) {
+                        if (d2 == d) continue;
+                        RFLU_TRY(EV(d2, b - 2, 0, &e));
+                        RFLU_HIP(hipStreamWaitEvent(g->P[d], e, 0));
+                    }
+                }
+            }
+        }
+        {
+            RFLU_HIP(hipSetDevice(g->devs[o]));
+            Handle* h = g->h[o];
+            if (b >= 1) {   // the owner's slice has received update b-1
+                RFLU_TRY(EV(o, b - 1, 1, &e));
+                RFLU_HIP(hipStreamWaitEvent(g->P[o], e, 0));
+            }
+            h->stream = g->P[o];
+            T* R = slabs[o];
+            Fact<T> f{h, R, lds[o], n, c.lc + c.w, g->ipiv[o], pivot};
+            f.sw_lo = c.lc;
+            f.sw_hi = c.lc + c.w;
+            f.roff = c.j0 - c.lc;
+            RFLU_TRY(f.rec(c.lc, c.lc + c.w));
+            RFLU_HIP(hipMemcpy2DAsync(g->pbuf[par][o], (size_t)c.w * sizeof(T), R + c.j0 * lds[o] + c.lc, (size_t)lds[o] * sizeof(T),
+                                      (size_t)c.w * sizeof(T), (size_t)rows, hipMemcpyDeviceToDevice, g->P[o]));
+            RFLU_HIP(hipMemcpyAsync(g->meta[par][o], g->ipiv[o] + c.j0, (size_t)c.w * sizeof(int64_t), hipMemcpyDeviceToDevice, g->P[o]));
+            RFLU_TRY(EV(o, b, 0, &e));
+            RFLU_HIP(hipEventRecord(e, g->P[o]));
+        }
+        if (D == 1) return RFLU_OK;
+        if (!g->fake) {   // the one exchange step of the path: ncclBroadcast of {panel, pivots} on the panel streams
+            RFLU_NCCL(g->rccl, g->rccl.GroupStart());
+            for (int d = 0; d < D; ++d) {
+                RFLU_NCCL(g->rccl, g->rccl.Broadcast(g->pbuf[par][d], g->pbuf[par][d], (size_t)rows * (size_t)c.w, ntype, o, g->comms[d], g->P[d]));
+                RFLU_NCCL(g->rccl, g->rccl.Broadcast(g->meta[par][d], g->meta[par][d], (size_t)c.w, ncclInt64, o, g->comms[d], g->P[d]));
+            }
+            RFLU_NCCL(g->rccl, g->rccl.GroupEnd());
+            for (int d = 0; d < D; ++d) {
+                if (d == o) continue;
+                RFLU_HIP(hipSetDevice(g->devs[d]));
+                RFLU_TRY(EV(d, b, 0, &e));
+                RFLU_HIP(hipEventRecord(e, g->P[d]));
+            }
+        } else {          // logical devices on one physical device: the "broadcast" is a device-to-device copy
+            hipEvent_t packed;
+            RFLU_TRY(EV(o, b, 0, &packed));
+            for (int d = 0; d < D; ++d) {
+                if (d == o) continue;
+                RFLU_HIP(hipSetDevice(g->devs[d]));
+                RFLU_HIP(hipStreamWaitEvent(g->P[d], packed, 0));
+                RFLU_HIP(hipMemcpyAsync(g->pbuf[par][d], g->pbuf[par][o], (size_t)rows * (size_t)c.w * sizeof(T), hipMemcpyDeviceToDevice, g->P[d]));
+                RFLU_HIP(hipMemcpyAsync(g->meta[par][d], g->meta[par][o], (size_t)c.w * sizeof(int64_t), hipMemcpyDeviceToDevice, g->P[d]));
+                RFLU_TRY(EV(d, b, 0, &e));
+                RFLU_HIP(hipEventRecord(e, g->P[d]));
+            }
+        }
+        return RFLU_OK;
+    };
+
+    RFLU_TRY(produce(0));
+    // a panel taller than this cannot run next to the bulk update (its cooperating workgroups need more CUs than the update
+    // stream's mask leaves free): its owner factors it BEFORE its own bulk update and catches up afterwards, while the
+    // other devices are already applying it
+    int64_t tall_rows = 32 * (int64_t)PANEL_THREADS;
+    if (const char* e = getenv("RFLU_MGPU_TALL_ROWS")) tall_rows = atoll(e);     // debugging knobs
+    const int dbg_sync = getenv("RFLU_MGPU_SYNC") ? atoi(getenv("RFLU_MGPU_SYNC")) : 0;
+    auto sync_all = [&]() -> int {
+        for (int d = 0; d < D; ++d) { RFLU_HIP(hipSetDevice(g->devs[d])); RFLU_HIP(hipDeviceSynchronize()); }
+        return RFLU_OK;
+    };
+    for (int64_t b = 0; b < nb; ++b) {
+        if (dbg_sync & 1) RFLU_TRY(sync_all());
+        const BlockCol& c = lay[b];
+        const int par = (int)(b & 1);
+        const int nxt_owner = (b + 1 < nb) ? lay[b + 1].owner : -1;
+        const bool tall_next = nxt_owner >= 0 && (n - lay[b + 1].j0) > tall_rows;
+        std::vector<int64_t> left_end(D, 0), right_start(D, 0), nxt_slice(D, 0);
+        hipEvent_t e;
+        // ---- phase 1: receive, pivots, and the slice of the next owner
+        for (int d = 0; d < D; ++d) {
+            RFLU_HIP(hipSetDevice(g->devs[d]));
+            Handle* h = g->h[d];
+            h->stream = g->U[d];
+            RFLU_TRY(EV(d, b, 0, &e));                       // packed (owner) / received (others)
+            RFLU_HIP(hipStreamWaitEvent(g->U[d], e, 0));
+            const T* pb = static_cast<const T*>(g->pbuf[par][d]);
+            if (d != c.owner)
+                RFLU_HIP(hipMemcpyAsync(g->ipiv[d] + c.j0, g->meta[par][d], (size_t)c.w * sizeof(int64_t), hipMemcpyDeviceToDevice, g->U[d]));
+            if (pivot) RFLU_TRY(launch_perm_build(h, g->ipiv[d], c.j0, c.j0 + c.w, n));
+            for (int64_t q = 0; q < b; ++q) if (lay[q].owner == d) left_end[d] += lay[q].w;
+            right_start[d] = left_end[d] + (d == c.owner ? c.w : 0);
+            if (d == nxt_owner) {   // this device owns block column b+1: bring exactly those columns up to date first
+                nxt_slice[d] = lay[b + 1].w;
+                RFLU_TRY(mgpu_update<T>(h, n, slabs[d], lds[d], pb, c.j0, c.w, right_start[d], nxt_slice[d], pivot));
+            }
+            RFLU_TRY(EV(d, b, 1, &e));
+            RFLU_HIP(hipEventRecord(e, g->U[d]));
+        }
+        if (dbg_sync & 2) RFLU_TRY(sync_all());
+        if (tall_next) {
+            RFLU_TRY(produce(b + 1));
+            RFLU_HIP(hipSetDevice(g->devs[nxt_owner]));
+            RFLU_TRY(EV(nxt_owner, b + 1, 0, &e));
+            RFLU_HIP(hipStreamWaitEvent(g->U[nxt_owner], e, 0));
+        }
+        // ---- phase 2: interchanges on the finished columns to the left, bulk update of the rest
+        for (int d = 0; d < D; ++d) {
+            RFLU_HIP(hipSetDevice(g->devs[d]));
+            Handle* h = g->h[d];
+            h->stream = g->U[d];
+            const T* pb = static_cast<const T*>(g->pbuf[par][d]);
+            if (pivot && left_end[d] > 0)
+                RFLU_TRY(launch_laswp<T>(h, slabs[d], lds[d], 0, left_end[d], c.j0 / NB, (c.j0 + c.w + NB - 1) / NB));
+            RFLU_TRY(mgpu_update<T>(h, n, slabs[d], lds[d], pb, c.j0, c.w, right_start[d] + nxt_slice[d],
+                                    ncols_loc[d] - right_start[d] - nxt_slice[d], pivot));
+            RFLU_TRY(EV(d, b, 2, &e));
+            RFLU_HIP(hipEventRecord(e, g->U[d]));
+        }
+        if (b + 1 < nb && !tall_next) RFLU_TRY(produce(b + 1));   // queued behind the slice update: overlaps with the bulk of update b
+    }
+    // drain, collect info (first zero pivot = smallest global index among the owners) and the error flags
+    int64_t first = 0, flags = 0;
+    for (int d = 0; d < D; ++d) {
+        RFLU_HIP(hipSetDevice(g->devs[d]));
+        Handle* h = g->h[d];
+        RFLU_HIP(hipStreamSynchronize(g->P[d]));
+        RFLU_HIP(hipStreamSynchronize(g->U[d]));
+        RFLU_HIP(hipMemcpy(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (h->info_pinned[0] != 0 && (first == 0 || h->info_pinned[0] < first)) first = h->info_pinned[0];
+        flags |= h->info_pinned[1];
+        h->stream = h->own_stream;
+    }
+    g->h[0]->info_pinned[1] = flags;
+    RFLU_TRY(panel_flags_status(g->h[0]));
+    if (ipiv_host) {
+        RFLU_HIP(hipSetDevice(g->devs[0]));
+        RFLU_HIP(hipMemcpy(ipiv_host, g->ipiv[0], (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
+    *info = first;
+    return RFLU_OK;
+}
+
+template <typename T>
+static int mgpu_fill(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, int64_t block, int64_t run, uint64_t seed,
+                     double diag_add)
+{
+    if (n <= 0 || block <= 0 || run <= 0) { set_error("mgpu fill: bad arguments"); return RFLU_ERR_ARG; }
+    std::vector<BlockCol> lay;
+    std::vector<int64_t> ncols_loc;
+    mgpu_layout(n, block, g->ndev, run, lay, ncols_loc);
+    DeviceGuard guard(g->devs[0]);
+    RFLU_HIP(guard.err);
+    for (const BlockCol& c : lay) {
+        RFLU_HIP(hipSetDevice(g->devs[c.owner]));
+        Handle* h = g->h[c.owner];
+        h->stream = h->own_stream;
+        RFLU_TRY(launch_fill_uniform<T>(h, slabs[c.owner] + c.lc, n, c.w, lds[c.owner], 1, seed, n, 0, c.j0, diag_add));
+    }
+    for (int d = 0; d < g->ndev; ++d) {
+        RFLU_HIP(hipSetDevice(g->devs[d]));
+        RFLU_HIP(hipStreamSynchronize(g->h[d]->own_stream));
+    }
+    return RFLU_OK;
+}
+
+}  // namespace rflu
+
+extern "C" {
+
+static Mgpu* MG(rflu_mgpu_t m) { return reinterpret_cast<Mgpu*>(m); }
+
+int rflu_mgpu_create(rflu_mgpu_t* out, int ndev, const int* devs)
+{
+    if (out == nullptr || ndev < 1 || ndev > 64 || devs == nullptr) { set_error("mgpu create: bad arguments"); return RFLU_ERR_ARG; }
+    *out = nullptr;
+    Mgpu* g = new (std::nothrow) Mgpu();
+    if (!g) { set_error("out of host memory"); return RFLU_ERR_ARG; }
+    g->ndev = ndev;
+    g->devs.assign(devs, devs + ndev);
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devs[i] == devs[j]) g->fake = true;
+    for (int par = 0; par < 2; ++par) {
+        g->pbuf[par].assign(ndev, nullptr);
+        g->pbuf_bytes[par].assign(ndev, 0);
+        g->meta[par].assign(ndev, nullptr);
+    }
+    g->meta_cap.assign(ndev, 0);
+    g->ipiv.assign(ndev, nullptr);
+    g->ipiv_cap.assign(ndev, 0);
+    g->U.assign(ndev, nullptr);
+    g->P.assign(ndev, nullptr);
+    g->ev.resize(ndev);
+    int rc = RFLU_OK;
+    for (int d = 0; d < ndev && rc == RFLU_OK; ++d) {
+        rflu_handle_t hh = nullptr;
+        rc = rflu_create(&hh, devs[d]);
+        if (rc == RFLU_OK) g->h.push_back(H(hh));
+    }
+    if (rc == RFLU_OK && ndev > 1 && !g->fake) {   // RCCL communicator over the distinct devices (single process)
+        rc = g->rccl.load();
+        if (rc == RFLU_OK) {
+            g->comms.assign(ndev, nullptr);
+            ncclResult_t e = g->rccl.CommInitAll(g->comms.data(), ndev, devs);
+            if (e != ncclSuccess) { set_error("ncclCommInitAll failed: %s", g->rccl.GetErrorString(e)); g->comms.clear(); rc = RFLU_ERR_HIP; }
+        }
+    }
+    if (rc != RFLU_OK) { (void)rflu_mgpu_destroy(reinterpret_cast<rflu_mgpu_t>(g)); return rc; }
+    *out = reinterpret_cast<rflu_mgpu_t>(g);
+    return RFLU_OK;
+}
+
+int rflu_mgpu_destroy(rflu_mgpu_t m)
+{
+    if (!m) return RFLU_OK;
+    Mgpu* g = MG(m);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (size_t d = 0; d < g->h.size(); ++d) {
+        (void)hipSetDevice(g->devs[d]);
+        (void)hipDeviceSynchronize();
+        for (int par = 0; par < 2; ++par) {
+            if (g->pbuf[par][d]) (void)hipFree(g->pbuf[par][d]);
+            if (g->meta[par][d]) (void)hipFree(g->meta[par][d]);
+        }
+        if (g->ipiv[d]) (void)hipFree(g->ipiv[d]);
+        for (hipEvent_t e : g->ev[d]) (void)hipEventDestroy(e);
+    }
+    for (ncclComm_t c : g->comms)
+        if (c) (void)g->rccl.CommDestroy(c);
+    for (Handle* h : g->h) (void)rflu_destroy(reinterpret_cast<rflu_handle_t>(h));
+    (void)hipSetDevice(prev);
+    delete g;
+    return RFLU_OK;
+}
+
+int rflu_mgpu_ndev(rflu_mgpu_t m) { return m ? MG(m)->ndev : 0; }
+int rflu_mgpu_is_fake(rflu_mgpu_t m) { return m ? (MG(m)->fake ? 1 : 0) : 0; }
+
+int64_t rflu_mgpu_local_cols(int64_t n, int64_t block, int ndev, int64_t run, int d)
+{
+    if (n < 0 || block <= 0 || ndev < 1 || run < 1 || d < 0 || d >= ndev) return -1;
+    std::vector<BlockCol> lay;
+    std::vector<int64_t> loc;
+    mgpu_layout(n, block, ndev, run, lay, loc);
+    return loc[d];
+}
+
+int rflu_getrf_f64_mgpu(rflu_mgpu_t m, int64_t n, double* const* slabs, const int64_t* lds, int64_t* ipiv_host, int pivot,
+                        int64_t block, int64_t run, int64_t* info)
+{
+    if (!m) { set_error("null multi-GPU handle"); return RFLU_ERR_ARG; }
+    return mgpu_getrf<double>(MG(m), n, slabs, lds, ipiv_host, pivot, block, run, info);
+}
+int rflu_getrf_f32_mgpu(rflu_mgpu_t m, int64_t n, float* const* slabs, const int64_t* lds, int64_t* ipiv_host, int pivot,
+                        int64_t block, int64_t run, int64_t* info)
+{
+    if (!m) { set_error("null multi-GPU handle"); return RFLU_ERR_ARG; }
+    return mgpu_getrf<float>(MG(m), n, slabs, lds, ipiv_host, pivot, block, run, info);
+}
+int rflu_mgpu_fill_uniform_f64(rflu_mgpu_t m, int64_t n, double* const* slabs, const int64_t* lds, int64_t block, int64_t run,
+                               uint64_t seed, double diag_add)
+{
+    if (!m) { set_error("null multi-GPU handle"); return RFLU_ERR_ARG; }
+    return mgpu_fill<double>(MG(m), n, slabs, lds, block, run, seed, diag_add);
+}
+int rflu_mgpu_fill_uniform_f32(rflu_mgpu_t m, int64_t n, float* const* slabs, const int64_t* lds, int64_t block, int64_t run,
+                               uint64_t seed, double diag_add)
+{
+    if (!m) { set_error("null multi-GPU handle"); return RFLU_ERR_ARG; }
+    return mgpu_fill<float>(MG(m), n, slabs, lds, block, run, seed, diag_add);
+}
+
 int rflu_profile_enable(rflu_handle_t handle, int enable)
 {
     CHECK_HANDLE(handle);

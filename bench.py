@@ -409,9 +409,14 @@ def main():
         if job is not None:
             check["residual_matvec"] = job.matvec_residual()
             check["info"] = int(job.info)
-        elif rank == 0:
-            check["residual_matvec"] = mgpu_matvec_residual(mg, n, slabs, lds, mlayout, args.block, run, pivot)
-            check["info"] = int(mg_info[0])
+        else:
+            regenerate()
+            barrier()
+            step()
+            barrier()
+            if rank == 0:
+                check["residual_matvec"] = mgpu_matvec_residual(mg, n, slabs, lds, mlayout, args.block, run, pivot)
+                check["info"] = int(mg_info[0])
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and single:

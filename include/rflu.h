@@ -151,6 +151,19 @@ int rflu_cm_to_rm_f32_dev(rflu_handle_t handle, int64_t m, int64_t n, const floa
 int rflu_rm_to_cm_f32_dev(rflu_handle_t handle, int64_t m, int64_t n, const float* R_rm, int64_t ldr, float* A_cm,
                           int64_t lda);
 
+/* ---- randomized butterfly pre-transform (the reference's 🦋 solver, src/butterflylu.jl) ----
+ * rflu_butterfly_mul_*: A <- U' A V in place (🦋mul!, src/butterflylu.jl:90-113), A column-major n x n on the device, n % 4
+ * == 0 (pad! first, :180-197), uv = the 4n random diagonal entries in the reference's layout (:93-108).  One streaming
+ * pass applies both butterfly levels.  After it a NoPivot factorization (rflu_getrf_*_dev with pivot = 0) is safe.
+ * rflu_butterfly_vec_*: X <- U' X (transpose_u != 0) or X <- V X (transpose_u == 0) for nrhs column vectors -- the two
+ * products around ldiv! in 🦋solve! (:50-52), applied as butterflies instead of dense matrices. */
+int rflu_butterfly_mul_f64_dev(rflu_handle_t handle, int64_t n, double* A_dev, int64_t lda, const double* uv_dev);
+int rflu_butterfly_mul_f32_dev(rflu_handle_t handle, int64_t n, float* A_dev, int64_t lda, const float* uv_dev);
+int rflu_butterfly_vec_f64_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, double* X_dev, int64_t ldx,
+                               const double* uv_dev, int transpose_u);
+int rflu_butterfly_vec_f32_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, float* X_dev, int64_t ldx,
+                               const float* uv_dev, int transpose_u);
+
 /* ---- synthetic input on device (bench / tests; not part of the reference's surface) ----
  * Fill the m x n sub-block starting at global (i0, j0) of an M_global-row uniform[0,1) matrix:
  * element (i,j) = u01(seed, (j0+j)*M_global + (i0+i)) -- bit-identical to oracle/rflu_oracle.c:rfo_uniform01.

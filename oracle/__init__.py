@@ -5,6 +5,9 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 """
 from .oracle import (  # noqa: F401
     build,
+    butterfly_materialize_uv,
+    butterfly_mul,
+    butterfly_mul_level,
     fill_uniform,
     generic_lufact,
     lib,

@@ -139,3 +139,63 @@ def residual(A: np.ndarray, F: np.ndarray, ipiv: np.ndarray):
     R = L @ U - A64[p, :]
     nrm = np.linalg.norm(A64)
     return float(np.max(np.abs(R))) if R.size else 0.0, float(np.linalg.norm(R) / nrm) if nrm > 0 else 0.0
+
+
+# ---- butterfly pre-transform: NumPy restatement of /root/reference/src/butterflylu.jl (test infrastructure) -----------------
+def butterfly_mul_level(A: np.ndarray, u: np.ndarray, v: np.ndarray) -> None:
+    """🦋mul_level! (src/butterflylu.jl:59-88), in place on the view A; same expressions in the same order."""
+    M, N = A.shape
+    mh, nh = M >> 1, N >> 1
+    A11, A21, A12, A22 = A[:mh, :nh].copy(), A[mh:, :nh].copy(), A[:mh, nh:].copy(), A[mh:, nh:].copy()
+    T1, T2, T3, T4 = A11 + A12, A21 + A22, A11 - A12, A21 - A22
+    C11, C21, C12, C22 = T1 + T2, T1 - T2, T3 + T4, T3 - T4
+    u1, u2 = u[:mh, None], u[mh:, None]
+    v1, v2 = v[None, :nh], v[None, nh:]
+    A[:mh, :nh] = u1 * C11 * v1
+    A[mh:, :nh] = u2 * C21 * v1
+    A[:mh, nh:] = u1 * C12 * v2
+    A[mh:, nh:] = u2 * C22 * v2
+
+
+def butterfly_mul(A: np.ndarray, uv: np.ndarray) -> np.ndarray:
+    """🦋mul! (src/butterflylu.jl:90-113): level 2 on the four quadrants, then level 1; in place, returns A."""
+    M = A.shape[0]
+    h = M >> 1
+    U1, V1, U2, V2 = uv[:h], uv[h:M], uv[M:M + h], uv[M + h:2 * M]
+    butterfly_mul_level(A[:h, :h], U1, V1)
+    butterfly_mul_level(A[h:, :h], U2, V1)
+    butterfly_mul_level(A[:h, h:], U1, V2)
+    butterfly_mul_level(A[h:, h:], U2, V2)
+    butterfly_mul_level(A, uv[2 * M:3 * M], uv[3 * M:4 * M])
+    return A
+
+
+def _bfly_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """🦋!(C, A::Diagonal, B::Diagonal) (src/butterflylu.jl:133-146): [Da Db; Da -Db]."""
+    n = a.size
+    C = np.zeros((2 * n, 2 * n), dtype=a.dtype)
+    i = np.arange(n)
+    C[i, i] = a
+    C[i + n, i] = a
+    C[i, i + n] = b
+    C[i + n, i + n] = -b
+    return C
+
+
+def butterfly_materialize_uv(uv: np.ndarray, M: int):
+    """materializeUV (src/butterflylu.jl:149-178): dense U = Bu2*Bu1, V = Bv2*Bv1."""
+    h = M >> 1
+    q = h >> 1
+    def halves(x):
+        k = x.size >> 1
+        return x[:k], x[k:]
+    U1, U2 = uv[:h], uv[2 * h:M + h]
+    V1, V2 = uv[h:2 * h], uv[3 * h:2 * h + M]
+    Uf, Vf = uv[2 * M:3 * M], uv[3 * M:4 * M]
+    Bu2 = np.zeros((M, M), dtype=uv.dtype)
+    Bu2[:h, :h] = _bfly_matrix(*halves(U1))
+    Bu2[h:, h:] = _bfly_matrix(*halves(U2))
+    Bv2 = np.zeros((M, M), dtype=uv.dtype)
+    Bv2[:h, :h] = _bfly_matrix(*halves(V1))
+    Bv2[h:, h:] = _bfly_matrix(*halves(V2))
+    return Bu2 @ _bfly_matrix(*halves(Uf)), Bv2 @ _bfly_matrix(*halves(Vf))

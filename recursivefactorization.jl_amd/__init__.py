@@ -22,7 +22,15 @@ from .lu import (  # noqa: F401
     normalize_pivot,
 )
 
+from .butterfly import (  # noqa: F401,E402
+    ButterflyWorkspace,
+    butterfly_mul_,
+    butterfly_solve_,
+    butterfly_workspace,
+)
+
 __all__ = [
+    "ButterflyWorkspace", "butterfly_workspace", "butterfly_solve_", "butterfly_mul_",
     "lu", "lu_", "ldiv_", "LU", "NotIPIV", "RowMaximum", "NoPivot", "Val", "Adjoint", "Transpose", "SingularException",
     "normalize_pivot", "last_path", "Handle", "RfluError", "default_handle", "NOPIVOT_NEGATIVE_INFO",
 ]

@@ -36,6 +36,8 @@ _TYPED = {
     "rflu_gemm_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64]),
     "rflu_cm_to_rm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64]),
     "rflu_rm_to_cm_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64]),
+    "rflu_butterfly_mul_{s}_dev": (c_int, [c_p, c_i64, c_p, c_i64, c_p]),
+    "rflu_butterfly_vec_{s}_dev": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_p, c_int]),
     "rflu_fill_uniform_{s}_dev": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_u64, c_i64, c_i64, c_i64, c_dbl]),
 }
 _PLAIN = {

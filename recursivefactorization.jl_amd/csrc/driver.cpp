@@ -858,6 +858,19 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out)
         RFLU_HIP(hipStreamSynchronize(H(handle)->stream));                                                            \
         return RFLU_OK;                                                                                               \
     }                                                                                                                 \
+    int rflu_butterfly_mul_##SFX##_dev(rflu_handle_t handle, int64_t n, T* A, int64_t lda, const T* uv)               \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        if (n > 0 && (A == nullptr || uv == nullptr)) { set_error("butterfly: null pointer"); return RFLU_ERR_ARG; }  \
+        return launch_butterfly_mul<T>(H(handle), n, A, lda, uv);                                                     \
+    }                                                                                                                 \
+    int rflu_butterfly_vec_##SFX##_dev(rflu_handle_t handle, int64_t n, int64_t nrhs, T* X, int64_t ldx, const T* uv, \
+                                       int transpose_u)                                                               \
+    {                                                                                                                 \
+        CHECK_HANDLE(handle);                                                                                         \
+        if (n > 0 && nrhs > 0 && (X == nullptr || uv == nullptr)) { set_error("butterfly: null pointer"); return RFLU_ERR_ARG; } \
+        return launch_butterfly_vec<T>(H(handle), n, nrhs, X, ldx, uv, transpose_u ? 0 : 1);                          \
+    }                                                                                                                 \
     int rflu_fill_uniform_##SFX##_dev(rflu_handle_t handle, T* A, int64_t m, int64_t n, int64_t ld, int row_major,    \
                                       uint64_t seed, int64_t M_global, int64_t i0, int64_t j0, double diag_add)       \
     {                                                                                                                 \

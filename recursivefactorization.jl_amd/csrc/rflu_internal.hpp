@@ -190,5 +190,10 @@ template <typename T>
 int launch_fill_uniform(Handle* h, T* A, int64_t m, int64_t n, int64_t ld, int row_major, uint64_t seed,
                         int64_t M_global, int64_t i0, int64_t j0, double diag_add);
 int launch_iota_ipiv(Handle* h, int64_t* ipiv, int64_t k0, int64_t n);
+// butterfly.hip: A <- U' A V (column-major, in place) and x <- U' x (mode 0) / x <- V x (mode 1)
+template <typename T>
+int launch_butterfly_mul(Handle* h, int64_t n, T* A, int64_t lda, const T* uv);
+template <typename T>
+int launch_butterfly_vec(Handle* h, int64_t n, int64_t nrhs, T* X, int64_t ldx, const T* uv, int mode);
 
 }  // namespace rflu

@@ -65,6 +65,7 @@ struct GemmArgs {
     int64_t ldc;
     int tiles_m, tiles_n;
     int vec_ok;  // operands 16-byte aligned with even strides: full tiles may use 16-byte loads
+    int flags;   // bit0: first operand slab requested BEFORE the C tile; bit1: non-temporal C accesses
 };
 
 // C_FIRST: the accumulators start as the C tile (its read overlaps with the first operand slabs, the epilogue only
@@ -144,6 +145,12 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
         }
     };
 
+    // The first operand slab is requested BEFORE the C tile: the memory counter retires in order, so the wait in front of
+    // sstore(0) then covers these few loads only and the 64 C loads of the tile keep flying behind the LDS fill, the barrier
+    // and the first MFMAs (each fragment is waited for where it is first used).
+    const bool early = (g.flags & 1) != 0;
+    const bool ntc = (g.flags & 2) != 0;
+    if (early) gload(0);
     // For a fixed (i,j,r) sixteen lanes cover 16 consecutive columns of one row of C.
     acc_t acc[4][4];
 #pragma unroll
@@ -155,13 +162,15 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wc * 64 + j * 16 + (lane & 15);
-                acc[i][j][r] = (C_FIRST && row < g.M && col < g.N) ? crow_p[j * 16] : T(0);
+                T cv = T(0);
+                if (C_FIRST && row < g.M && col < g.N) cv = ntc ? __builtin_nontemporal_load(crow_p + j * 16) : crow_p[j * 16];
+                acc[i][j][r] = cv;
             }
         }
     }
 
     const int nk = (g.K + G_BK - 1) / G_BK;
-    gload(0);
+    if (!early) gload(0);
     sstore(0);
     __syncthreads();
 
@@ -201,7 +210,14 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int col = n0 + wc * 64 + j * 16 + (lane & 15);
-                    if (col < g.N) crow_p[j * 16] = C_FIRST ? acc[i][j][r] : crow_p[j * 16] - acc[i][j][r];
+                    if (col < g.N) {
+                        if (C_FIRST) {
+                            if (ntc) __builtin_nontemporal_store(acc[i][j][r], crow_p + j * 16);
+                            else crow_p[j * 16] = acc[i][j][r];
+                        } else {
+                            crow_p[j * 16] = crow_p[j * 16] - acc[i][j][r];
+                        }
+                    }
                 }
             }
         }
@@ -321,6 +337,8 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
     constexpr int VW = 16 / (int)sizeof(T);
     g.vec_ok = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0) && (lda % VW == 0) &&
                (ldb % VW == 0);
+    static const int gemm_flags = [] { const char* e = getenv("RFLU_GEMM_FLAGS"); return e ? atoi(e) : 1; }();
+    g.flags = gemm_flags;
     {   // small K, few tiles: the latency-optimised kernel (measured crossover, scripts/microbench_gemm_small.py)
         static const int skinny_max_k = [] { const char* e = getenv("RFLU_SKINNY_MAXK"); return e ? atoi(e) : 128; }();
         if (g.vec_ok && (K == S_KC || K == 2 * S_KC) && K <= skinny_max_k && N <= 2 * K) {

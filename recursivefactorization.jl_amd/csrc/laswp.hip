@@ -12,13 +12,17 @@
 
 namespace rflu {
 
-constexpr int LW_COLS = 64;           // columns per workgroup (one lane per column)
-constexpr int LW_ROWS_PER_THREAD = (2 * NB) / 4;  // 4 waves share the <=128 moves of a chunk
+constexpr int LW_COLS = 16;           // columns per workgroup: 16 lanes x 8 bytes = one 128-byte line of every row it touches
+constexpr int LW_RSUB = 64 / LW_COLS; // row slots per wave (a wave covers 4 rows x 16 columns per access)
+constexpr int LW_ROWS_PER_THREAD = (2 * NB) / (4 * LW_RSUB);  // 4 waves x 4 row slots share the <=128 moves of a chunk
 
 // inv_nb > 0: extra workgroups (the last inv_cnt) invert the leaves' 64x64 diagonal blocks for the fused TRSMs that follow
 // (trsm.hip) -- they ride along with the leaf's interchange launch instead of costing a dependent launch of their own.
 // A third column range [c2, c2+ncolsC) receives only the chunks after the first: for a pair leaf (panel.hip) these are
 // leaf A's own columns, which still need leaf B's interchanges.
+// Geometry: narrow column strips (16 columns) give 4x the workgroups of a 64-column strip -- a full-width launch at N=16384
+// is ~1000 workgroups instead of 248 (less than one per CU), so four times as many row loads are in flight per dependent
+// {move list -> rows -> barrier -> stores} round of a chunk.
 template <typename T>
 __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA,
                                                     int64_t c1, int64_t ncolsB, int64_t c2, int64_t ncolsC,
@@ -40,23 +44,25 @@ __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t l
         return;
     }
     // the column ranges are covered by one launch (left and right of a panel, and a pair's first leaf)
+    const int cl = lane & (LW_COLS - 1), rsub = lane / LW_COLS;
     int64_t col;
     bool active;
     int first = chunk0;
     if ((int64_t)blockIdx.x < blocksA) {
-        const int64_t off = (int64_t)blockIdx.x * LW_COLS + lane;
+        const int64_t off = (int64_t)blockIdx.x * LW_COLS + cl;
         col = c0 + off;
         active = off < ncolsA;
     } else if ((int64_t)blockIdx.x < blocksA + blocksB) {
-        const int64_t off = ((int64_t)blockIdx.x - blocksA) * LW_COLS + lane;
+        const int64_t off = ((int64_t)blockIdx.x - blocksA) * LW_COLS + cl;
         col = c1 + off;
         active = off < ncolsB;
     } else {
-        const int64_t off = ((int64_t)blockIdx.x - blocksA - blocksB) * LW_COLS + lane;
+        const int64_t off = ((int64_t)blockIdx.x - blocksA - blocksB) * LW_COLS + cl;
         col = c2 + off;
         active = off < ncolsC;
         first = chunk0 + 1;
     }
+    const int ebase = wave * LW_RSUB + rsub;   // this thread's moves: ebase, ebase + 16, ...
     T v[LW_ROWS_PER_THREAD];
     for (int t = first; t < chunk1; ++t) {
         // the whole move list of the chunk in four coalesced loads (lane e holds entries e and e+64) ...
@@ -64,18 +70,19 @@ __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t l
         const int s0 = pm_src[(size_t)t * 2 * NB + lane], s1 = pm_src[(size_t)t * 2 * NB + NB + lane];
         const int d0 = pm_dst[(size_t)t * 2 * NB + lane], d1 = pm_dst[(size_t)t * 2 * NB + NB + lane];
         // ... so that all row loads of the chunk are in flight together (one memory latency, not one per row)
+        int dst[LW_ROWS_PER_THREAD];
 #pragma unroll
         for (int i = 0; i < LW_ROWS_PER_THREAD; ++i) {
-            const int e = wave + 4 * i;  // wave-uniform
-            const int src = (e < NB) ? __builtin_amdgcn_readlane(s0, e & 63) : __builtin_amdgcn_readlane(s1, e & 63);
+            const int e = ebase + 16 * i;   // < 128; the same for the 16 lanes of a row slot
+            const int src = (e < NB) ? __shfl(s0, e & 63) : __shfl(s1, e & 63);
+            dst[i] = (e < NB) ? __shfl(d0, e & 63) : __shfl(d1, e & 63);
             if (e < cnt && active) v[i] = R[(int64_t)src * ld + col];
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < LW_ROWS_PER_THREAD; ++i) {
-            const int e = wave + 4 * i;
-            const int dst = (e < NB) ? __builtin_amdgcn_readlane(d0, e & 63) : __builtin_amdgcn_readlane(d1, e & 63);
-            if (e < cnt && active) R[(int64_t)dst * ld + col] = v[i];
+            const int e = ebase + 16 * i;
+            if (e < cnt && active) R[(int64_t)dst[i] * ld + col] = v[i];
         }
         __syncthreads();
     }

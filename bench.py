@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--blocksize", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the in-schedule timer pass and the block-size sweep (profiling runs)")
     ap.add_argument("--cpu-n", type=int, default=6144, help="size of the bounded CPU-baseline sample (~10-30 s of CPU work)")
     ap.add_argument("--block", type=int, default=512, help="block-column width of the multi-GPU layout")
     return ap.parse_args()
@@ -330,7 +331,7 @@ def main():
     # what the GEMM achieves next to the critical-path stream, and the HBM rate of the row interchanges (laswp)
     laswp = None
     sweep = None
-    if single:
+    if single and not args.no_extras:
         regenerate()
         barrier()
         h.profile_enable(2)

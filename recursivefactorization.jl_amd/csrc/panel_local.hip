@@ -255,11 +255,11 @@ struct XLds {
 
 // All waves, between the bookkeeping of column c and barrier B(c): search of column c+1 inside the wave; lane 0 leaves the
 // wave's record {key, position, a_{c+1}, a_{c+2}, l_c of the winning lane}.
-template <typename T>
+template <typename T, int PW>
 __device__ __forceinline__ void x_record(XLds<T>* sh, int tid, T a1, T a2, T l, unsigned pos, bool act)
 {
     const int lane = tid & 63, wave = uni(tid >> 6);
-    if (wave < PANEL_WAVES) {
+    if (wave < PW) {
         unsigned hi, lo, p = act ? pos : POS_NONE;
         IKey<T>::split(a1, act, hi, lo);
         unsigned mh = hi, ml = lo;
@@ -277,15 +277,15 @@ __device__ __forceinline__ void x_record(XLds<T>* sh, int tid, T a1, T a2, T l, 
 }
 
 // Communication wave after barrier B(c): the workgroup's candidate for column c+1 from the 8 wave records; its header leaves at once.
-template <typename T, int AUX>
+template <typename T, int AUX, int PW>
 __device__ __forceinline__ void x_w0_publish(XLds<T>* sh, u64* scratch, unsigned epoch, int c1, int g, int lane)
 {
     scratch = uni(scratch);
     epoch = uni(epoch);
     c1 = uni(c1);
     g = uni(g);
-    const int r = lane & (PANEL_WAVES - 1);
-    const bool has = lane < PANEL_WAVES;   // lanes 0..7 hold the 8 wave records
+    const int r = lane & (PW - 1);
+    const bool has = lane < PW;   // lanes 0..PW-1 hold the wave records
     unsigned hi = has ? sh->rhi[r] : 0u, lo = has ? sh->rlo[r] : 0u, cp = has ? sh->rpos[r] : POS_NONE;
     const T a1 = sh->ra1[r], a2 = sh->ra2[r], l = sh->rl[r];
     const int wl = wave_argmax_i<IKey<T>::TWO>(hi, lo, cp);
@@ -400,7 +400,7 @@ struct XState {
 };
 
 // Step C >= 0: column C.  C == -1 is the prologue: records of column 0, H(0), first exchange.
-template <typename T, int C, int AUX>
+template <typename T, int C, int AUX, int PW>
 __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a)[NB], T& lprev, XState& st, PermState& perm,
                                        int g, int tid)
 {
@@ -433,7 +433,7 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
                 if constexpr (C + 1 < NB) a[C + 1] -= l * h.wu;
             }
         }
-        if (g == 0 && wave == PANEL_WAVES - 1 && h.win != POS_NONE)
+        if (g == 0 && wave == PW - 1 && h.win != POS_NONE)
             perm_state_step(perm, p.r0, C, __builtin_amdgcn_readfirstlane((int)h.win), lane);
     }
     const bool more = C + 1 < p.w;   // workgroup-uniform
@@ -442,7 +442,7 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
             T a2 = T(0);
             if constexpr (C + 2 < NB) a2 = a[C + 2];
             if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 1, g, tid);
-            x_record<T>(sh, tid, a[C + 1], a2, l, st.pos, st.act);   // ends with barrier B
+            x_record<T, PW>(sh, tid, a[C + 1], a2, l, st.pos, st.act);   // ends with barrier B
             if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 2, g, tid);
             if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 3, g, tid);
         }
@@ -472,20 +472,23 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
     }
 }
 
-template <typename T, int C0, int C1, int AUX>
+template <typename T, int C0, int C1, int AUX, int PW>
 struct XSteps {
     static __device__ __forceinline__ void run(const PanelArgs<T>& p, XLds<T>* sh, T (&a)[NB], T& lprev, XState& st,
                                                PermState& perm, int g, int tid)
     {
         if constexpr (C0 < C1) {
-            x_step<T, C0, AUX>(p, sh, a, lprev, st, perm, g, tid);
-            XSteps<T, C0 + 1, C1, AUX>::run(p, sh, a, lprev, st, perm, g, tid);
+            x_step<T, C0, AUX, PW>(p, sh, a, lprev, st, perm, g, tid);
+            XSteps<T, C0 + 1, C1, AUX, PW>::run(p, sh, a, lprev, st, perm, g, tid);
         }
     }
 };
 
-template <typename T, bool LOCAL>
-__global__ void __launch_bounds__(PANEL_THREADS + 64) panel_pivot_local_kernel(LocalArgs<T> la)
+// PW = row waves per workgroup: 8 (512 rows, two row waves per SIMD) for tall panels; 4 (256 rows, ONE row wave per SIMD: the
+// dependent instruction chain between the barriers runs without a second wave sharing the issue slots) while the panel's
+// rows still fit 32 such workgroups
+template <typename T, bool LOCAL, int PW>
+__global__ void __launch_bounds__(PW * 64 + 64) panel_pivot_local_kernel(LocalArgs<T> la)
 {
     constexpr int AUX = LOCAL ? 0 : AUX_SC1;
     // LOCAL: the participants are the blocks that RUN on the chosen XCD.  A launch spreads its blocks round-robin over the
@@ -498,12 +501,12 @@ __global__ void __launch_bounds__(PANEL_THREADS + 64) panel_pivot_local_kernel(L
     XLds<T>* const sh = &s_lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = (int)(blockIdx.x / (unsigned)la.stride);
-    const int row = p.r0 + g * PANEL_THREADS + tid;
+    const int row = p.r0 + g * (PW * 64) + tid;
     // waves 0..7 own one matrix row per thread; wave 8 is the communication wave (no rows): it alone runs the exchange, at
     // raised priority, so none of that sits on a wave that also has row work to do
-    if (wave == PANEL_WAVES) __builtin_amdgcn_s_setprio(3);
+    if (wave == PW) __builtin_amdgcn_s_setprio(3);
     XState st;
-    st.act = row < p.m && wave < PANEL_WAVES;
+    st.act = row < p.m && wave < PW;
     st.pos = st.act ? (unsigned)row : POS_NONE;
     st.updprev = false;
     st.dead = false;
@@ -516,22 +519,22 @@ __global__ void __launch_bounds__(PANEL_THREADS + 64) panel_pivot_local_kernel(L
     __syncthreads();
     T lprev = T(0);
     PermState perm = perm_state_init(lane);
-    if (wave == PANEL_WAVES) {
+    if (wave == PW) {
         // communication wave: a run-time loop (no row registers, no static indices), everything inline -- a non-inlined
         // call would wait for the acknowledgement of the stores just issued (s_waitcnt vmcnt(0) at every call boundary)
         for (int c1 = 0; c1 < p.w; ++c1) {
             barrier_lds_only();   // B(c1 - 1): the wave records of column c1 are in LDS
-            x_w0_publish<T, AUX>(sh, p.scratch, p.epoch, c1, g, lane);
+            x_w0_publish<T, AUX, PW>(sh, p.scratch, p.epoch, c1, g, lane);
             x_w0_exchange<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, c1, p.r0, g, lane);
             barrier_lds_only();   // A(c1)
             if (sh->dead) break;
         }
     } else {
-        XSteps<T, -1, NB, AUX>::run(p, sh, a, lprev, st, perm, g, tid);
+        XSteps<T, -1, NB, AUX, PW>::run(p, sh, a, lprev, st, perm, g, tid);
         store_row_direct<T>(p.R, p.ld, st.pos, p.c0, p.w, a);
     }
     __syncthreads();
-    if (g == 0 && wave == PANEL_WAVES - 1) {
+    if (g == 0 && wave == PW - 1) {
         const int chunk = p.r0 / NB;
         perm_state_finish(perm, p.r0, lane, sh->rows, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
                           p.pm_src + (size_t)chunk * 2 * NB);
@@ -541,22 +544,34 @@ __global__ void __launch_bounds__(PANEL_THREADS + 64) panel_pivot_local_kernel(L
 // Launch the leaf on the blocks b with b % stride == sel of a grid of G*stride workgroups.  local != 0: plain-store
 // records (all participants must share an XCD: stride 8); local == 0: sc1 records, any placement.
 template <typename T>
-int launch_panel_local(Handle* h, const PanelArgs<T>& p, int stride, int sel, int want_xcc, int local)
+int launch_panel_local(Handle* h, const PanelArgs<T>& p0, int stride, int sel, int want_xcc, int local)
 {
     LocalArgs<T> la;
-    la.p = p;
+    la.p = p0;
     la.stride = stride;
     la.sel = sel;
     la.want_xcc = want_xcc;
-    const dim3 grid((unsigned)(p.G * stride));
+    // 256-row workgroups (one row wave per SIMD) while they still number at most 32 -- the CUs the lookahead schedule keeps
+    // free for the panel; taller panels use 512-row workgroups.  RFLU_PANEL_PW=8 forces the latter.
+    static const int force_pw = [] { const char* e = getenv("RFLU_PANEL_PW"); return e ? atoi(e) : 0; }();
+    const int64_t rows = (int64_t)p0.m - p0.r0;
+    const int g4 = (int)((rows + 255) / 256);
+    const bool pw4 = force_pw == 4 || (force_pw == 0 && g4 <= 32 && !h->coop_launch);
+    if (pw4) la.p.G = g4;
+    const dim3 grid((unsigned)(la.p.G * stride));
     if (h->coop_launch && stride == 1) {   // launch-time residency check by the runtime (opt-in: +15-19 us per launch)
         void* kargs[] = {&la};
-        RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false>), grid,
-                                            dim3(PANEL_THREADS + 64), kargs, 0, h->stream));
+        RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 8>), grid,
+                                            dim3(8 * 64 + 64), kargs, 0, h->stream));
         return RFLU_OK;
     }
-    if (local) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true>), grid, dim3(PANEL_THREADS + 64), 0, h->stream, la);
-    else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false>), grid, dim3(PANEL_THREADS + 64), 0, h->stream, la);
+    if (pw4) {
+        if (local) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true, 4>), grid, dim3(4 * 64 + 64), 0, h->stream, la);
+        else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 4>), grid, dim3(4 * 64 + 64), 0, h->stream, la);
+    } else {
+        if (local) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true, 8>), grid, dim3(8 * 64 + 64), 0, h->stream, la);
+        else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 8>), grid, dim3(8 * 64 + 64), 0, h->stream, la);
+    }
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }
@@ -567,11 +582,11 @@ static int panel_local_resident_limit_t(int num_cus)
     int worst = 1 << 30;
     auto ask = [&](const void* fn) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, PANEL_THREADS + 64, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 8 * 64 + 64, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
         worst = std::min(worst, nb * num_cus);
     };
-    ask(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, true>));
-    ask(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false>));
+    ask(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, true, 8>));
+    ask(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 8>));
     return worst;
 }
 

@@ -14,7 +14,9 @@ Workloads (BASELINE.json configs): 1 GPU -> n = 16384 (config 2, the one the 70 
 Extra objects on the JSON line:
   roofline     dominant kernel = the MFMA GEMM update (schur_complement!): algorithmic 2*M*N*K flops of every launch of
                one profiled factorization / their summed HIP-event durations, against the fp64 MFMA peak
-  cpu_baseline the CPU restatement of the reference (oracle/, "port", 1 core) timed on this host on a bounded sample
+  cpu_baseline the CPU restatement of the reference (oracle/, "port") built -march=native and timed on this host: threaded
+               (thread = Val(true)) headline + serial figures at n = 512 (config 0) and n = 4096, on a bounded sample
+  laswp        HBM rate of the row interchanges in the shipped schedule; sweep: block sizes 64/128/256 (config 2)
 """
 from __future__ import annotations
 
@@ -53,33 +55,44 @@ def parse_args():
 
 
 def cpu_baseline(cpu_n: int):
-    """Time the oracle (CPU restatement of the reference's lu!, same nsplit/blocksize/threshold) on this host."""
+    """Time the oracle (CPU restatement of the reference's lu!, same nsplit/blocksize/threshold) on this host: built with
+    -march=native on this machine, serial (thread = Val(false)) and threaded (thread = Val(true): the reference threads
+    apply_permutation!, the TRSM and schur_complement!; the panel stays serial).  Bounded to ~10-30 s of CPU work."""
     import numpy as np
 
     import oracle as O
 
-    out = {}
-    # BASELINE config 0 verbatim: lu!(rand(512,512)) Float64 partial pivot, single thread
-    A = O.np_uniform(512, 512, SEED)
-    O.lu(A)
-    ts = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        O.lu(A)
-        ts.append(time.perf_counter() - t0)
-    out["n512_gflops"] = round(2 * 512**3 / 3 / sorted(ts)[len(ts) // 2] / 1e9, 3)
-    A = O.np_uniform(cpu_n, cpu_n, SEED)
-    t0 = time.perf_counter()
-    _, ipiv, _ = O.lu(A)
-    dt = time.perf_counter() - t0
-    gf = 2 * cpu_n**3 / 3 / dt / 1e9
-    res = {"value": round(gf, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
-           "sample": f"one lu!(A) of the n={cpu_n} Float64 uniform matrix (seed {SEED}) by oracle/rflu_oracle.c in {dt:.1f} s; "
-                     f"config-0 size n=512: {out['n512_gflops']} GFLOP/s (median of 5)",
+    native = O.use_native()   # oracle/_native/: compiled here for this host's cores (falls back to the shipped x86-64-v3 build)
+    cores = min(64, os.cpu_count() or 1)
+
+    def timed(n, threads, reps=1):
+        O.set_threads(threads)
+        A = O.np_uniform(n, n, SEED)
+        ts, ip = [], None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            _, ip, _ = O.lu(A)
+            ts.append(time.perf_counter() - t0)
+        dt = sorted(ts)[len(ts) // 2]
+        return round(2 * n**3 / 3 / dt / 1e9, 3), dt, ip
+
+    O.set_threads(1)
+    O.lu(O.np_uniform(512, 512, SEED))                      # warm-up
+    n512, _, _ = timed(512, 1, reps=5)                      # BASELINE config 0 verbatim: lu!(rand(512,512)), Float64, pivoted, serial
+    s4096, _, _ = timed(4096, 1)                            # the size that overlaps the GPU runs (config 1), serial
+    t4096, _, _ = timed(4096, cores)
+    gf, dt, ipiv = timed(cpu_n, cores)                      # headline sample (also provides the pivots for the parity check)
+    O.set_threads(1)
+    res = {"value": gf, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+           "sample": f"one lu!(A, thread = Val(true)) of the n={cpu_n} Float64 uniform matrix (seed {SEED}) by oracle/rflu_oracle.c "
+                     f"(OpenMP over the reference's threaded loops, {cores} threads) in {dt:.2f} s",
+           "serial_n512_gflops": n512, "serial_n4096_gflops": s4096, "threaded_n4096_gflops": t4096,
+           "build": "-O3 -march=native on this host" if native else "-O3 -march=x86-64-v3 (shipped build)",
            "host_cpus": os.cpu_count()}
     try:  # context only: LAPACK getrf on all host cores
         import scipy.linalg as sla
 
+        A = O.np_uniform(cpu_n, cpu_n, SEED)
         t0 = time.perf_counter()
         sla.lapack.dgetrf(A)
         res["lapack_getrf_allcores_gflops"] = round(2 * cpu_n**3 / 3 / (time.perf_counter() - t0) / 1e9, 1)

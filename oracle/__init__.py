@@ -15,5 +15,7 @@ from .oracle import (  # noqa: F401
     np_uniform,
     nsplit,
     residual,
+    set_threads,
     unpack_lu,
+    use_native,
 )

@@ -27,11 +27,33 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def use_native() -> bool:
+    """Switch to a -march=native build made on THIS machine (oracle/_native/, not shipped): for the CPU-baseline timing on
+    the GPU box's host cores.  Returns False (and keeps the portable build) if the compiler is unavailable."""
+    global _lib, _SO
+    try:
+        # always rebuilt (-B): a copy compiled for another machine's instruction set must never be picked up
+        subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "native"])
+    except (OSError, subprocess.CalledProcessError):
+        return False
+    _SO = os.path.join(_HERE, "_native", "librflu_oracle.so")
+    _lib = None
+    return True
+
+
+def set_threads(n: int) -> None:
+    """1 = the reference's thread = Val(false); n > 1 = Val(true) on n cores (results do not depend on n)."""
+    lib().rfo_set_threads(int(n))
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        build()
+        if not _SO.endswith(os.path.join("_native", "librflu_oracle.so")):
+            build()
         L = ctypes.CDLL(_SO)
+        L.rfo_set_threads.restype = None
+        L.rfo_set_threads.argtypes = [ctypes.c_int]
         for sfx in ("f64", "f32"):
             getattr(L, f"rfo_lu_{sfx}").restype = _i64
             getattr(L, f"rfo_lu_{sfx}").argtypes = [_p, _i64, _i64, _i64, _p, ctypes.c_int, _i64, _i64]

@@ -59,6 +59,13 @@ void rfo_fill_uniform_f32(float* A, int64_t m, int64_t n, int64_t lda, uint64_t 
         for (int64_t i = 0; i < m; ++i) A[i + j * lda] = (float)rfo_uniform01(seed, (uint64_t)(j * m + i));
 }
 
+/* thread = Val(true) of the reference (Polyester @batch / @tturbo in apply_permutation!, TRSM and schur_complement!; the
+ * panel stays serial, src/lu.jl:164-175,268): 1 = serial (Val(false)).  The threaded loops run over independent columns, so
+ * results do not depend on the thread count. */
+static int rfo_threads = 1;
+void rfo_set_threads(int n) { rfo_threads = n > 1 ? n : 1; }
+int rfo_get_threads(void) { return rfo_threads; }
+
 #define T double
 #define SFX f64
 #define TABS fabs

@@ -10,9 +10,16 @@
 // image (one barrier per slab): global loads for slab t+1 are issued before the 64 MFMAs of slab t and written to the
 // other LDS buffer after them, so HBM/L2 latency hides behind ~4096 cycles of matrix work per wave.
 //
-// LDS images (strides chosen so every fragment read is bank-conflict free, MI355X_MICROARCH.md "LDS"):
-//   As[i][k], row stride SA = BK+2 : lanes (i=l&15, k=l>>4) of a 32-lane group hit 32 distinct 8-byte bank pairs
-//   Bs[k][j], row stride SB = BN+16: the two k-rows read by a 32-lane group sit 32 banks apart
+// LDS images.  hipcc pairs the fragment reads into ds_read2_b64 and the staging writes are ds_write_b64: both are serviced
+// in groups of 16 CONSECUTIVE lanes on a 32-bank map, bank = (byte address / 4) % 32 (MI355X_MICROARCH.md "LDS").  Round 1
+// laid the images out for the 64-bank / 32-lane rule of a lone ds_read_b64 and paid for it: SQ_LDS_BANK_CONFLICT 8.1e9 cycles
+// where the vendor BLAS kernel of the same tile shape shows 0 (scripts/pmc_gemm.sh), the B staging writes 8-way conflicted.
+//   As[i][k], row stride SA = BK+1 = 17 doubles: the 16 lanes of a group read rows i..i+15 at one k -> dword 34*i, and
+//             34*i mod 32 = 2*i: 16 distinct bank pairs; the staging writes (8 rows x 2 k-halves per group) land on
+//             2*r + {0,16}: distinct as well
+//   Bs[k][c + (c >> 4)], row stride SB = 144 doubles: a one-double gap after every 16 columns.  A group's fragment read
+//             covers 16 consecutive columns of one block (contiguous, all 32 banks once); a staging write has lane l at
+//             columns 8l..8l+7 -> dword 16*l + 2*(l/2) + 2e = {2a, 16+2a}: distinct bank pairs (was: 16*l -> 8-way)
 // Two workgroups per CU (2 x 72 KiB LDS, <=256 VGPRs) keep each SIMD's matrix pipe fed across barriers.
 //
 // Roofline: bound = fp64 MFMA, 78.6 TFLOP/s chip peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz);
@@ -49,7 +56,7 @@ struct Mfma<float> {
 };
 
 constexpr int G_BM = 128, G_BN = 128, G_BK = 16;
-constexpr int G_SA = G_BK + 2;
+constexpr int G_SA = G_BK + 1;
 constexpr int G_SB = G_BN + 16;
 constexpr int G_STAGE = G_BM * G_SA + G_BK * G_SB;  // elements per LDS stage
 constexpr int G_GROUP_M = 8;                        // tile rows walked together (L2 reuse of the B panel)
@@ -141,7 +148,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
             // C_FIRST: the accumulators start as C itself (loaded straight into them, no dependent VALU before the first
             // slab), so the products must enter negated; otherwise plain A and the subtraction happens in the epilogue
             As[a_row * G_SA + a_kb + e] = C_FIRST ? -ra[e] : ra[e];
-            Bs[b_k * G_SB + b_jb + e] = rb[e];
+            Bs[b_k * G_SB + b_jb + (b_jb >> 4) + e] = rb[e];
         }
     };
 
@@ -175,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
     __syncthreads();
 
     const int a_frag = (wr * 64 + (lane & 15)) * G_SA + (lane >> 4);
-    const int b_frag = (lane >> 4) * G_SB + wc * 64 + (lane & 15);
+    const int b_frag = (lane >> 4) * G_SB + wc * 68 + (lane & 15);   // column c sits at c + (c >> 4): wc*64 -> wc*68
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -188,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 a[t] = As[a_frag + t * 16 * G_SA + kk * 4];
-                b[t] = Bs[b_frag + kk * 4 * G_SB + t * 16];
+                b[t] = Bs[b_frag + kk * 4 * G_SB + t * 17];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)

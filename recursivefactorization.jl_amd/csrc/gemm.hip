@@ -238,11 +238,14 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 // 64x64 tile and issues EVERY load of a 64-wide K chunk at once:
 //   * A never touches LDS: with the K index permuted as k = 16*kk + s (kk = lane>>4, s = MFMA step), the A operand of
 //     lane (i, kk) for the 16 steps of a chunk is 16 CONTIGUOUS elements of row i -- four 16-byte loads;
-//   * B (64 x 64 per chunk) goes through LDS once (odd row stride: conflict-free for the permuted rows);
+//   * B (64 x 64 per chunk) goes through LDS once.  Layout Bs[k][c + (c >> 4)], row stride 68 doubles: a staging write has the
+//     16 lanes of a group at rows r..r+3 x column blocks q = 0..3 -> dword 136*r + 34*q = 8*r + 2*q (mod 32): 16 distinct bank
+//     pairs (the old odd stride 65 put the four column blocks of a row on the same banks: 4-way conflicts, 38 % of the
+//     kernel's LDS cycles); a fragment read covers 16 consecutive columns of one block;
 //   * the C tile is read into registers up front, so one memory round trip covers everything the tile needs.
 // The sum over k is the same set of products; only the order inside the MFMA accumulation differs.
 constexpr int S_BM = 64, S_BN = 64, S_KC = 64;
-constexpr int S_SB = S_BN + 1;
+constexpr int S_SB = S_BN + 4;   // 64 columns + one gap double per 16-column block: column c sits at c + (c >> 4)
 
 template <typename T, int NCHUNK>
 __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs<T> g)
@@ -303,7 +306,7 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs<T> g)
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Bs[c][brow * S_SB + bcol + e] = rb[c][e];
+        for (int e = 0; e < 16; ++e) Bs[c][brow * S_SB + bcol + (bcol >> 4) + e] = rb[c][e];   // bank-conflict free, see below
     }
     __syncthreads();
     acc_t acc[4];
@@ -315,7 +318,7 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs<T> g)
         for (int st = 0; st < 16; ++st) {
             const T* brow_p = &Bs[c][(kk * 16 + st) * S_SB + li];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = Mfma<T>::run(ra[c][st], brow_p[j * 16], acc[j]);
+            for (int j = 0; j < 4; ++j) acc[j] = Mfma<T>::run(ra[c][st], brow_p[j * 17], acc[j]);
         }
     }
 #pragma unroll

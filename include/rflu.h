@@ -69,6 +69,9 @@ int rflu_last_path(rflu_handle_t handle);
  * panel kernels issued on another stream always find 32 free CUs.  Used by the lookahead drivers (single- and
  * multi-GPU) for the bulk trailing updates. */
 int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out);
+/* Measurement aid (scripts/microbench_*.py): about `usec` microseconds of register-only MFMA load, launched asynchronously on
+ * the CU-masked update stream.  Not part of the reference interface. */
+int rflu_debug_heat(rflu_handle_t handle, double usec);
 
 /* ---- the boundary: lu!(A, ipiv, pivot; blocksize) on HOST buffers (caller-owned, column-major) ----
  * Replaces src/lu.jl:114-126 (recursive path + unblocked fallback) for Float64 / Float32.

@@ -213,6 +213,26 @@ static int panel_flags_status(Handle* h)
     return RFLU_OK;
 }
 
+// C-ABI GEMM.  RFLU_GEMM_MASKED=<reserve> (measurement only): run it on the CU-masked update stream of the lookahead
+// schedule and wait for it, so that scripts/microbench_gemm_k.py can time the kernel on 256 - reserve CUs.
+int get_ustream(Handle* h, int reserve, hipStream_t* out);
+template <typename T>
+static int gemm_public(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C,
+                       int64_t ldc)
+{
+    const char* e = getenv("RFLU_GEMM_MASKED");
+    if (e == nullptr) return launch_gemm<T>(h, M, N, K, A, lda, B, ldb, C, ldc);
+    hipStream_t U, saved = h->stream;
+    RFLU_TRY(get_ustream(h, atoi(e), &U));
+    RFLU_HIP(hipStreamSynchronize(saved));
+    h->stream = U;
+    const int rc = launch_gemm<T>(h, M, N, K, A, lda, B, ldb, C, ldc);
+    h->stream = saved;
+    RFLU_TRY(rc);
+    RFLU_HIP(hipStreamSynchronize(U));
+    return RFLU_OK;
+}
+
 template <typename T>
 struct Fact {
     Handle* h;
@@ -316,6 +336,27 @@ int get_ustream(Handle* h, int reserve, hipStream_t* out)
     return RFLU_OK;
 }
 
+// The complement of get_ustream's mask: a stream confined to the `reserve` CUs the update stream never touches.
+// While the factorization is update-bound the critical path has time to spare, and every workgroup of ITS GEMMs that lands
+// on a shared CU delays the update by the same amount (measured: the 15872^2 x 512 update runs at 46 TFLOP/s next to an
+// unconfined panel recursion, 55 TFLOP/s alone) -- so in that phase the critical path is kept on its own CUs.
+static int get_pstream(Handle* h, int reserve, hipStream_t* out)
+{
+    const int r = reserve / 32;
+    if (reserve % 32 != 0 || r < 1 || r > 7) { set_error("CU reservation %d not in 32..224 step 32", reserve); return RFLU_ERR_ARG; }
+    if (!h->pstreams[r]) {
+        uint32_t mask[8];
+        const int words = std::min(8, (h->num_cus + 31) / 32);
+        for (int i = 0; i < 8; ++i) mask[i] = (i < r && i < words) ? 0xffffffffu : 0u;
+        if (words <= r || hipExtStreamCreateWithCUMask(&h->pstreams[r], (uint32_t)words, mask) != hipSuccess) {
+            (void)hipGetLastError();
+            RFLU_HIP(hipStreamCreateWithFlags(&h->pstreams[r], hipStreamNonBlocking));
+        }
+    }
+    *out = h->pstreams[r];
+    return RFLU_OK;
+}
+
 // ---- cost model of the lookahead schedule (microseconds; calibrated on MI355X) ----
 static double model_panel_us(int64_t rows, int64_t W)
 {
@@ -363,6 +404,22 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
     T* R = f.R;
     const int64_t nblk = (mn + W - 1) / W;
     hipEvent_t ev;
+    // The critical path moves between the caller's stream and a stream confined to the reserved CUs (get_pstream); h->stream
+    // follows it, and is put back on every way out of this function.
+    struct Restore { Handle* h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, h->stream};
+    const hipStream_t userS = h->stream;
+    int64_t confine_rows = sizeof(T) == 8 ? 11264 : 1 << 30;   // panels at least this tall run confined (update-bound phase)
+    if (const char* e = getenv("RFLU_CONFINE_ROWS")) confine_rows = atoll(e);
+    auto move_P = [&](hipStream_t to, int64_t b) -> int {
+        if (to == P) return RFLU_OK;
+        hipEvent_t e0;
+        RFLU_TRY(get_event(h, 4 * b + 0, &e0));
+        RFLU_HIP(hipEventRecord(e0, P));
+        RFLU_HIP(hipStreamWaitEvent(to, e0, 0));
+        P = to;
+        h->stream = to;
+        return RFLU_OK;
+    };
 
     auto update = [&](hipStream_t st, int64_t j0, int64_t jb, int64_t c0, int64_t c1) -> int {
         // apply block column [j0, j0+jb) to columns [c0, c1): interchanges, block-row solve, Schur update
@@ -398,6 +455,14 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
 
     for (int64_t b = 0; b < nblk; ++b) {
         const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
+        {
+            const int64_t g_b = (m - j0 + PANEL_THREADS - 1) / PANEL_THREADS;
+            const int res_b = std::max<int>(min_reserve, int((std::max<int64_t>(g_b, 1) + 31) / 32 * 32));
+            hipStream_t to = userS;
+            if (b > 0 && prev_overlapped && m - j0 >= confine_rows && res_b == 32)   // taller panels: restB needs the whole GPU
+                RFLU_TRY(get_pstream(h, res_b, &to));
+            RFLU_TRY(move_P(to, b));
+        }
         // ---- panel b on P: Toledo recursion on the block column, interchanges confined to its own columns ----
         f.sw_lo = j0;
         f.sw_hi = je;
@@ -490,6 +555,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
         prev_overlapped = true;
     }
     RFLU_TRY(flush_pending());
+    RFLU_TRY(move_P(userS, nblk));
     f.sw_lo = 0;
     f.sw_hi = -1;
     f.gate = nullptr;
@@ -729,6 +795,8 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipStream_t us : h->ustreams)
         if (us) (void)hipStreamDestroy(us);
+    for (hipStream_t ps : h->pstreams)
+        if (ps) (void)hipStreamDestroy(ps);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     for (auto& r : h->async_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : h->async_pool) (void)hipEventDestroy(e);
@@ -761,6 +829,19 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out)
     RFLU_TRY(get_ustream(H(handle), 32, &us));
     *hip_stream_out = reinterpret_cast<void*>(us);
     return RFLU_OK;
+}
+
+// measurement only (scripts/microbench_*): `usec` of register-only MFMA load on the CU-masked update stream, asynchronously
+int rflu_debug_heat(rflu_handle_t handle, double usec)
+{
+    CHECK_HANDLE(handle);
+    Handle* h = H(handle);
+    hipStream_t us, saved = h->stream;
+    RFLU_TRY(get_ustream(h, 32, &us));
+    h->stream = us;
+    const int rc = launch_heat(h, 224, usec);
+    h->stream = saved;
+    return rc;
 }
 
 #define DEFINE_TYPED(SFX, T)                                                                                          \
@@ -824,7 +905,7 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out)
                                  const T* B, int64_t ldb, T* C, int64_t ldc)                                          \
     {                                                                                                                 \
         CHECK_HANDLE(handle);                                                                                         \
-        return launch_gemm<T>(H(handle), M, N, K, A, lda, B, ldb, C, ldc);                                            \
+        return gemm_public<T>(H(handle), M, N, K, A, lda, B, ldb, C, ldc);                                            \
     }                                                                                                                 \
     int rflu_cm_to_rm_##SFX##_dev(rflu_handle_t handle, int64_t m, int64_t n, const T* A, int64_t lda, T* R,          \
                                   int64_t ldr)                                                                        \

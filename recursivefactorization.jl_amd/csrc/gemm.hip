@@ -386,4 +386,41 @@ template int launch_gemm<double>(Handle*, int64_t, int64_t, int64_t, const doubl
 template int launch_gemm<float>(Handle*, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*,
                                 int64_t);
 
+
+// ---- clock keeper ----------------------------------------------------------------------------------------------------
+// Register-only fp64 MFMA loop, no memory traffic: `wgs` workgroups of 256 threads spin for `iters` x 64 MFMAs per wave.
+// MI355X power management lowers the clock while the chip is lightly loaded (a panel on 32 CUs) and takes ~15 ms of
+// sustained load to bring it back (scripts/microbench_gemm_seq.py: a 3 ms idle gap costs the next GEMM 11 %); see
+// DESIGN.md "clocks".  Operands are lane-dependent non-trivial values: with zeros the power draw -- and the effect -- vanish.
+__global__ void __launch_bounds__(256) heat_kernel(int iters, double* sink)
+{
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    double a = 0.37 + 0.001 * lane, b = -0.61 + 0.002 * lane;
+    acc_t c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, c3, 0, 0, 0);
+        }
+        a = -a;
+    }
+    const double r = c0[0] + c1[1] + c2[2] + c3[3];
+    if (r == 12345.678 && sink) sink[0] = r;   // never true: keeps the loop alive
+}
+
+// ~`usec` microseconds of MFMA load on `cus` CUs of the stream h->stream (64 MFMAs x 64 clocks per iteration per wave,
+// one wave per SIMD, at a nominal 2.4 GHz)
+int launch_heat(Handle* h, int cus, double usec)
+{
+    const int iters = (int)(usec * 2400.0 / (64.0 * 64.0));
+    if (iters <= 0 || cus <= 0) return RFLU_OK;
+    hipLaunchKernelGGL(heat_kernel, dim3((unsigned)cus), dim3(256), 0, h->stream, iters, (double*)nullptr);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
 }  // namespace rflu

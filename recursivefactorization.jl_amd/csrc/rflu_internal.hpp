@@ -51,6 +51,7 @@ struct Handle {
     // second stream for the lookahead driver: the deferred trailing updates run here, restricted by a CU mask to
     // 224 of the 256 CUs so that the cooperative panel kernels of the critical path always find 32 free CUs
     hipStream_t ustreams[8] = {};     // ustreams[r]: CU mask leaving 32*r CUs to the critical path (r = 1..7)
+    hipStream_t pstreams[8] = {};     // pstreams[r]: the complement -- exactly those 32*r CUs (critical path of the update-bound phase)
     std::vector<hipEvent_t> events;   // reusable, timing disabled
     int last_path = RFLU_PATH_NONE;
     int num_cus = 256;
@@ -148,6 +149,7 @@ int ensure_bookkeeping(Handle* h, int64_t rows);
 int ensure_buffer(void** ptr, size_t* cap, size_t need);  // grow-only device buffer (hipFree + hipMalloc)
 
 // ---- kernel launchers (each returns an rflu_status); all pointers are device pointers in R layout -----------------------
+int launch_heat(Handle* h, int cus, double usec);   // gemm.hip: clock keeper
 template <typename T>
 int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C,
                 int64_t ldc);

@@ -72,6 +72,9 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out);
 /* Measurement aid (scripts/microbench_*.py): about `usec` microseconds of register-only MFMA load, launched asynchronously on
  * the CU-masked update stream.  Not part of the reference interface. */
 int rflu_debug_heat(rflu_handle_t handle, double usec);
+/* Measurement aid (scripts/gate_trace.py): with RFLU_GATE_TRACE=1 in the environment the leaf-wise schedule stamps the wall
+ * clock (100 MHz ticks) when each stream passes each leaf; copies the 3 x 4096 stamps to `out` (host). */
+int rflu_debug_gate_stamps(rflu_handle_t handle, long long* out);
 
 /* ---- the boundary: lu!(A, ipiv, pivot; blocksize) on HOST buffers (caller-owned, column-major) ----
  * Replaces src/lu.jl:114-126 (recursive path + unblocked fallback) for Float64 / Float32.

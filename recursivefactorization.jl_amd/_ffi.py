@@ -50,6 +50,7 @@ _PLAIN = {
     "rflu_last_path": (c_int, [c_p]),
     "rflu_update_stream": (c_int, [c_p, ctypes.POINTER(c_p)]),
     "rflu_debug_heat": (c_int, [c_p, ctypes.c_double]),
+    "rflu_debug_gate_stamps": (c_int, [c_p, c_p]),
     "rflu_mgpu_create": (c_int, [ctypes.POINTER(c_p), c_int, ctypes.POINTER(c_int)]),
     "rflu_mgpu_destroy": (c_int, [c_p]),
     "rflu_mgpu_ndev": (c_int, [c_p]),

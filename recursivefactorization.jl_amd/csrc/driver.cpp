@@ -21,6 +21,7 @@
 #include <new>
 
 #include "rflu_internal.hpp"
+#include <chrono>
 
 namespace rflu {
 
@@ -315,11 +316,27 @@ static int get_event(Handle* h, size_t idx, hipEvent_t* ev)
 // An update stream leaves `reserve` CUs (a multiple of 32, 32..224) to the critical-path stream so that the cooperative
 // panel kernel (one 512-thread workgroup per CU) finds all its workgroups a home at once.  Streams are created once per
 // reservation and kept for the life of the handle.
+static int get_masked_stream(Handle* h, hipStream_t* slot, int r);
 int get_ustream(Handle* h, int reserve, hipStream_t* out)
 {
     const int r = reserve / 32;
     if (reserve % 32 != 0 || r < 1 || r > 7) { set_error("CU reservation %d not in 32..224 step 32", reserve); return RFLU_ERR_ARG; }
-    if (!h->ustreams[r]) {
+    RFLU_TRY(get_masked_stream(h, &h->ustreams[r], r));
+    *out = h->ustreams[r];
+    return RFLU_OK;
+}
+// side stream `which` (0/1) of the leaf-wise schedule: the same CUs as the update stream of that reservation
+static int get_sstream(Handle* h, int which, int reserve, hipStream_t* out)
+{
+    const int r = reserve / 32;
+    if (reserve % 32 != 0 || r < 1 || r > 7 || which < 0 || which > 1) { set_error("bad side stream request"); return RFLU_ERR_ARG; }
+    RFLU_TRY(get_masked_stream(h, &h->sstreams[which][r], r));
+    *out = h->sstreams[which][r];
+    return RFLU_OK;
+}
+static int get_masked_stream(Handle* h, hipStream_t* slot, int r)
+{
+    if (!*slot) {
         // CU mask bits are enumerated round-robin over the 8 XCDs (scripts/probes/cumask.hip): bits 0..31 are 4 CUs of
         // every XCD, and so on.  A mask that empties an XCD is ignored by the runtime, so whole 32-bit words are cleared.
         // The mask covers the CUs the device actually reports (num_cus / 32 words); callers only ask for a reservation
@@ -327,19 +344,18 @@ int get_ustream(Handle* h, int reserve, hipStream_t* out)
         uint32_t mask[8];
         const int words = std::min(8, (h->num_cus + 31) / 32);
         for (int i = 0; i < 8; ++i) mask[i] = (i < r || i >= words) ? 0u : 0xffffffffu;
-        if (words <= r || hipExtStreamCreateWithCUMask(&h->ustreams[r], (uint32_t)words, mask) != hipSuccess) {
+        if (words <= r || hipExtStreamCreateWithCUMask(slot, (uint32_t)words, mask) != hipSuccess) {
             (void)hipGetLastError();
-            RFLU_HIP(hipStreamCreateWithFlags(&h->ustreams[r], hipStreamNonBlocking));
+            RFLU_HIP(hipStreamCreateWithFlags(slot, hipStreamNonBlocking));
         }
     }
-    *out = h->ustreams[r];
     return RFLU_OK;
 }
 
 // The complement of get_ustream's mask: a stream confined to the `reserve` CUs the update stream never touches.
-// While the factorization is update-bound the critical path has time to spare, and every workgroup of ITS GEMMs that lands
-// on a shared CU delays the update by the same amount (measured: the 15872^2 x 512 update runs at 46 TFLOP/s next to an
-// unconfined panel recursion, 55 TFLOP/s alone) -- so in that phase the critical path is kept on its own CUs.
+// While the factorization is update-bound the critical path has time to spare, and the workgroups of ITS GEMMs that land on
+// shared CUs delay the update (scripts/microbench_gemm_vs_rec.py: -2 % on the masked 15872 x 14848 x 512 GEMM) -- so in that
+// phase the critical path is kept on its own CUs (N=16384: 88.1 -> 86.8 ms).
 static int get_pstream(Handle* h, int reserve, hipStream_t* out)
 {
     const int r = reserve / 32;
@@ -567,6 +583,189 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
     return RFLU_OK;
 }
 
+// Leaf-wise schedule: the critical path is nothing but the chain of cooperative leaves.
+//
+// The recursion's merges (solve + Schur update of the right half) and the block-column lookahead put ~640 us of small
+// dependent launches between the leaves of every 512-column block (scripts/trace_timeline.sh) -- as much as a third of the
+// late, panel-bound phase.  Here every leaf g (64 columns) is applied right-looking, and only the 64 columns the NEXT leaf
+// needs stay on the critical-path stream:
+//   P  : leaf g -> {interchanges of leaf g on columns LA = [c0+64, c0+128), inverse of its diagonal block} -> evP[g]
+//        -> [wait: leaf g-1 applied to LA by a side stream] solve + update of LA (K = 64) -> leaf g+1 ...
+//   S1 : [wait evP[g]] leaf g applied to the rest of its own block column          -> evS1[g]
+//   S2 : [wait evP[g]; first leaf of a block: wait evU1[b-1]] ... to the next block column   -> evS2[g]
+//   U  : once per block column b, after its last leaf: [wait evS1, evS2] the deferred interchanges on the columns to the
+//        left, then block column b (K = W) applied to everything right of block column b+1 -- block column b+2 first
+//        (evU1[b]) -- exactly the update stream of factor_lookahead.
+// STATUS: opt-in (RFLU_LEAFWISE=1), parity-tested, NOT the default.  Measured at N=16384: 115-118 ms against 87 ms for
+// factor_lookahead (93 ms with rocprofv3 attached, which changes how the queues are served).  The critical-path stream's
+// kernels add up to ~225 us per leaf but it passes a leaf only every ~400 us (scripts/gate_trace.py): six dependent launches
+// per leaf on one queue, next to three queues whose heads are spinning gate kernels.  hipEvent edges instead of gates cost
+// 40-50 us of bubble per record/wait on the hot stream (136 ms); hipStreamWaitValue64/WriteValue64: 124 ms.  What the idea
+// needs is fewer launches on P (gates folded into the interchange kernel, solve + update fused) -- DESIGN.md "next".
+// S1/S2/U share the CU mask that keeps the panel's CUs free.  Every column receives the same eliminations in the same order
+// as in reckernel! (src/lu.jl:189-263); inside a block column the Schur complement is accumulated 64 pivots at a time instead
+// of in the recursion's growing chunks, so factors agree with the one-stream path to rounding, pivots exactly.
+template <typename T>
+static int factor_leafwise(Fact<T>& f, int64_t W)
+{
+    Handle* h = f.h;
+    const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
+    T* R = f.R;
+    const hipStream_t userS = h->stream;
+    struct Restore { Handle* h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, userS};
+    hipStream_t P = userS;
+    const int64_t nblk = (mn + W - 1) / W, nleaf = (mn + NB - 1) / NB;
+    const size_t EB = 3 * (size_t)nleaf;   // events: leaf g -> 3g (evP), 3g+1 (evS1), 3g+2 (evS2); block b -> EB+2b (evU1), EB+2b+1 (evUend)
+    // the panel's workgroups must not share CUs with the side streams' kernels: the critical path lives on the reserved CUs
+    int64_t confine_rows = 0;
+    if (const char* e = getenv("RFLU_CONFINE_ROWS")) confine_rows = atoll(e);
+    auto reserve_for = [&](int64_t rows) {
+        const int64_t g = (std::max<int64_t>(rows, 1) + PANEL_THREADS - 1) / PANEL_THREADS;
+        return std::max<int>(32, int((g + 31) / 32 * 32));
+    };
+    auto wait_on = [&](hipStream_t st, size_t idx) -> int {
+        hipEvent_t e;
+        RFLU_TRY(get_event(h, idx, &e));
+        RFLU_HIP(hipStreamWaitEvent(st, e, 0));
+        return RFLU_OK;
+    };
+    auto record_on = [&](hipStream_t st, size_t idx) -> int {
+        hipEvent_t e;
+        RFLU_TRY(get_event(h, idx, &e));
+        RFLU_HIP(hipEventRecord(e, st));
+        return RFLU_OK;
+    };
+    // leaf (rows r0.., columns c0..c0+w) applied to columns [a, b): interchanges (optional), block-row solve, Schur update
+    auto apply_leaf = [&](hipStream_t st, int64_t c0, int64_t w, int64_t a, int64_t b, bool swaps) -> int {
+        if (b <= a) return RFLU_OK;
+        hipStream_t saved = h->stream;
+        h->stream = st;
+        int rc = RFLU_OK;
+        if (swaps && f.pivot) rc = launch_laswp<T>(h, R, ld, a, b - a, c0 / NB, c0 / NB + 1);
+        if (rc == RFLU_OK) rc = launch_trsm_inv64<T>(h, w, b - a, f.linv_at(c0), R + c0 * ld + a, ld);
+        if (rc == RFLU_OK && m > c0 + w)
+            rc = launch_gemm<T>(h, m - c0 - w, b - a, w, R + (c0 + w) * ld + c0, ld, R + c0 * ld + a, ld, R + (c0 + w) * ld + a, ld);
+        h->stream = saved;
+        return rc;
+    };
+    auto update = [&](hipStream_t st, int64_t j0, int64_t jb, int64_t c0, int64_t c1) -> int {
+        if (c1 <= c0) return RFLU_OK;
+        hipStream_t saved = h->stream;
+        h->stream = st;
+        int rc = RFLU_OK;
+        const int64_t je = j0 + jb;
+        if (f.pivot) rc = launch_laswp<T>(h, R, ld, c0, c1 - c0, j0 / NB, (je + NB - 1) / NB);
+        if (rc == RFLU_OK) rc = trsm_rec<T>(h, jb, c1 - c0, R + j0 * ld + j0, ld, R + j0 * ld + c0, ld, f.linv_at(j0));
+        if (rc == RFLU_OK && m > je)
+            rc = launch_gemm<T>(h, m - je, c1 - c0, jb, R + je * ld + j0, ld, R + j0 * ld + c0, ld, R + je * ld + c0, ld);
+        h->stream = saved;
+        return rc;
+    };
+    hipStream_t Uprev = nullptr, S1prev = nullptr, S2prev = nullptr;
+    const unsigned long long gbase = h->gate_epoch;
+    h->gate_epoch += (unsigned long long)nleaf + 2;
+    auto val = [&](int64_t g) { return gbase + (unsigned long long)g + 1; };
+    if (getenv("RFLU_GATE_TRACE") && !h->gate_stamps) {
+        RFLU_HIP(hipMalloc((void**)&h->gate_stamps, 3 * 4096 * sizeof(long long)));
+        RFLU_HIP(hipMemset(h->gate_stamps, 0, 3 * 4096 * sizeof(long long)));
+    }
+    auto stamp = [&](int which, int64_t g) -> long long* { return (h->gate_stamps && g < 4096) ? h->gate_stamps + which * 4096 + g : nullptr; };
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
+        const int64_t bend = std::min(j0 + W, n), wend = std::min(j0 + 2 * W, n);
+        const int res = reserve_for(m - j0);
+        hipStream_t S1, S2;
+        RFLU_TRY(get_sstream(h, 0, res, &S1));
+        RFLU_TRY(get_sstream(h, 1, res, &S2));
+        {   // the critical path runs on the reserved CUs while the update stream is the bottleneck (see get_pstream)
+            hipStream_t to = userS;
+            if (m - j0 >= confine_rows && res == 32) RFLU_TRY(get_pstream(h, res, &to));
+            if (to != P) {
+                RFLU_TRY(record_on(P, EB + 2 * (size_t)nblk + (size_t)b));
+                RFLU_TRY(wait_on(to, EB + 2 * (size_t)nblk + (size_t)b));
+                P = to;
+                h->stream = to;
+            }
+        }
+        const int64_t g0 = j0 / NB, nl = (jb + NB - 1) / NB;
+        for (int64_t i = 0; i < nl; ++i) {
+            const int64_t g = g0 + i, c0 = j0 + i * NB, w = std::min<int64_t>(NB, je - c0);
+            RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, f.ipiv, f.pivot));
+            const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);
+            if (la1 > la0 && g > 0) {   // leaf g-1 reached LA through a side stream: its own block's, or the next block's
+                const int64_t bendp = std::min(((c0 - NB) / W + 1) * W, n);
+                RFLU_TRY(launch_gate_wait(h, h->gate_ptr[la0 < bendp ? 1 : 2], val(g - 1)));
+            }
+            if (f.pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0)));
+            else RFLU_TRY(launch_diag_inv<T>(h, w, R + c0 * ld + c0, ld, f.linv_at(c0)));
+            RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g), stamp(0, g)));
+            RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
+            // ---- side stream 1: the rest of this block column ----
+            h->stream = S1;
+            int rc = launch_gate_wait(h, h->gate_ptr[0], val(g));
+            if (rc == RFLU_OK && i == 0 && b > 0) {   // these columns were last written by the previous block's S2; S1 may be a new stream
+                rc = launch_gate_wait(h, h->gate_ptr[2], val(g - 1));
+                if (rc == RFLU_OK && S1 != S1prev) rc = launch_gate_wait(h, h->gate_ptr[1], val(g - 1));
+            }
+            if (rc == RFLU_OK) rc = apply_leaf(S1, c0, w, la1, bend, true);
+            h->stream = S1;
+            if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g), stamp(1, g));
+            // ---- side stream 2: the next block column ----
+            h->stream = S2;
+            if (rc == RFLU_OK) rc = launch_gate_wait(h, h->gate_ptr[0], val(g));
+            if (rc == RFLU_OK && i == 0 && b > 0) {   // block column b+1 holds U(b-1)'s update; S2 may be a new stream
+                hipEvent_t e;
+                rc = get_event(h, EB + 2 * (size_t)(b - 1), &e);
+                if (rc == RFLU_OK && hipStreamWaitEvent(S2, e, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); rc = RFLU_ERR_HIP; }
+                if (rc == RFLU_OK && S2 != S2prev) rc = launch_gate_wait(h, h->gate_ptr[2], val(g - 1));
+            }
+            if (rc == RFLU_OK) rc = apply_leaf(S2, c0, w, std::max(la1, bend), wend, true);
+            h->stream = S2;
+            if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[2], val(g), stamp(2, g));
+            h->stream = P;
+            RFLU_TRY(rc);
+        }
+        S1prev = S1;
+        S2prev = S2;
+        // ---- U(b): everything right of block column b+1, and the interchanges nobody needed until now ----
+        hipStream_t U;
+        RFLU_TRY(get_ustream(h, reserve_for(m - je), &U));
+        const int64_t glast = g0 + nl - 1;
+        {
+            h->stream = U;
+            int rc = launch_gate_wait(h, h->gate_ptr[1], val(glast));
+            if (rc == RFLU_OK) rc = launch_gate_wait(h, h->gate_ptr[2], val(glast));
+            h->stream = P;
+            RFLU_TRY(rc);
+        }
+        if (Uprev && Uprev != U) RFLU_TRY(wait_on(U, EB + 2 * (size_t)(b - 1) + 1));
+        if (f.pivot) {
+            hipStream_t saved = h->stream;
+            h->stream = U;
+            int rc = RFLU_OK;
+            for (int64_t i = 0; i + 1 < nl && rc == RFLU_OK; ++i)   // leaf i's columns: the later leaves' interchanges
+                rc = launch_laswp<T>(h, R, ld, j0 + i * NB, NB, g0 + i + 1, g0 + nl);
+            if (rc == RFLU_OK && j0 > 0) rc = launch_laswp<T>(h, R, ld, 0, j0, g0, g0 + nl);
+            h->stream = saved;
+            RFLU_TRY(rc);
+        }
+        const int64_t p1e = std::min(wend + W, n);
+        RFLU_TRY(update(U, j0, jb, wend, p1e));
+        RFLU_TRY(record_on(U, EB + 2 * (size_t)b));
+        RFLU_TRY(update(U, j0, jb, p1e, n));
+        RFLU_TRY(record_on(U, EB + 2 * (size_t)b + 1));
+        Uprev = U;
+    }
+    if (P != userS) {
+        RFLU_TRY(record_on(P, EB + 3 * (size_t)nblk));
+        RFLU_TRY(wait_on(userS, EB + 3 * (size_t)nblk));
+        P = userS;
+        h->stream = userS;
+    }
+    RFLU_TRY(wait_on(userS, EB + 2 * (size_t)(nblk - 1) + 1));
+    return RFLU_OK;
+}
+
 // Factor the row-major m x n matrix R in place (see rflu.h for `blocksize`).
 template <typename T>
 static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* ipiv, int pivot, int64_t blocksize,
@@ -597,7 +796,16 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
         RFLU_TRY(f.rec(0, mn));
     } else if (!h->prof && h->num_cus == 256) {   // the CU reservation of the two-stream schedule is laid out for 8 x 32 CUs
         h->last_path = RFLU_PATH_HIP_LOOKAHEAD;
-        RFLU_TRY(factor_lookahead<T>(f, round_up(blocksize, NB)));
+        // RFLU_LEAFWISE=1: the experimental leaf-wise schedule (correct and parity-tested; measured slower, see factor_leafwise)
+        const char* lw = getenv("RFLU_LEAFWISE");
+        const int leafwise = lw ? atoi(lw) : 0;
+        const int64_t Wb = round_up(blocksize, NB);
+        const auto t_enq0 = std::chrono::steady_clock::now();
+        if (leafwise && Wb >= 2 * NB && (m + PANEL_THREADS - 1) / PANEL_THREADS <= 64) RFLU_TRY(factor_leafwise<T>(f, Wb));
+        else RFLU_TRY(factor_lookahead<T>(f, Wb));
+        if (getenv("RFLU_TIME_ENQUEUE"))
+            fprintf(stderr, "[rflu] host enqueue time %.2f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count());
         fat_tail_done = true;  // the block-column updates already reached the columns right of the square part
     } else {
         h->last_path = RFLU_PATH_HIP_BLOCKED;
@@ -754,6 +962,9 @@ int rflu_create(rflu_handle_t* handle, int device)
     }
     h->stream = h->own_stream;
     RFLU_HIP(hipMalloc((void**)&h->info_dev, 2 * sizeof(int64_t)));
+    RFLU_HIP(hipMalloc((void**)&h->gates, 8 * sizeof(unsigned long long)));
+    RFLU_HIP(hipMemset(h->gates, 0, 8 * sizeof(unsigned long long)));
+    for (int i = 0; i < 3; ++i) h->gate_ptr[i] = h->gates + i;
     RFLU_HIP(hipHostMalloc((void**)&h->info_pinned, 2 * sizeof(int64_t)));
     h->pscratch_bytes = panel_scratch_bytes();
     RFLU_HIP(hipMalloc((void**)&h->pscratch, h->pscratch_bytes));
@@ -790,6 +1001,8 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->linv_tmp) (void)hipFree(h->linv_tmp);
     if (h->pscratch) (void)hipFree(h->pscratch);
     if (h->info_dev) (void)hipFree(h->info_dev);
+    if (h->gates) (void)hipFree(h->gates);
+    if (h->gate_stamps) (void)hipFree(h->gate_stamps);
     if (h->info_pinned) (void)hipHostFree(h->info_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -797,6 +1010,9 @@ int rflu_destroy(rflu_handle_t handle)
         if (us) (void)hipStreamDestroy(us);
     for (hipStream_t ps : h->pstreams)
         if (ps) (void)hipStreamDestroy(ps);
+    for (auto& row : h->sstreams)
+        for (hipStream_t ss : row)
+            if (ss) (void)hipStreamDestroy(ss);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     for (auto& r : h->async_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : h->async_pool) (void)hipEventDestroy(e);
@@ -832,6 +1048,15 @@ int rflu_update_stream(rflu_handle_t handle, void** hip_stream_out)
 }
 
 // measurement only (scripts/microbench_*): `usec` of register-only MFMA load on the CU-masked update stream, asynchronously
+// measurement only: copy the RFLU_GATE_TRACE stamps (3 x 4096 wall-clock ticks, 100 MHz) to the host
+int rflu_debug_gate_stamps(rflu_handle_t handle, long long* out)
+{
+    CHECK_HANDLE(handle);
+    if (!H(handle)->gate_stamps) { set_error("no gate trace (set RFLU_GATE_TRACE=1)"); return RFLU_ERR_ARG; }
+    RFLU_HIP(hipMemcpy(out, H(handle)->gate_stamps, 3 * 4096 * sizeof(long long), hipMemcpyDeviceToHost));
+    return RFLU_OK;
+}
+
 int rflu_debug_heat(rflu_handle_t handle, double usec)
 {
     CHECK_HANDLE(handle);

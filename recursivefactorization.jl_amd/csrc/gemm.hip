@@ -351,7 +351,8 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
     g.flags = gemm_flags;
     {   // small K, few tiles: the latency-optimised kernel (measured crossover, scripts/microbench_gemm_small.py)
         static const int skinny_max_k = [] { const char* e = getenv("RFLU_SKINNY_MAXK"); return e ? atoi(e) : 128; }();
-        if (g.vec_ok && (K == S_KC || K == 2 * S_KC) && K <= skinny_max_k && N <= 2 * K) {
+        static const int skinny_wide = [] { const char* e = getenv("RFLU_SKINNY_WIDE"); return e ? atoi(e) : 0; }();
+        if (g.vec_ok && (K == S_KC || K == 2 * S_KC) && K <= skinny_max_k && (N <= 2 * K || (skinny_wide && K == S_KC))) {
             g.tiles_m = (int)((M + S_BM - 1) / S_BM);
             g.tiles_n = (int)((N + S_BN - 1) / S_BN);
             ProfScope ps(h, RFLU_K_GEMM_SMALL, 2.0 * (double)M * (double)N * (double)K,

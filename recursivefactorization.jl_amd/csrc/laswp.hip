@@ -237,4 +237,44 @@ int launch_iota_ipiv(Handle* h, int64_t* ipiv, int64_t k0, int64_t n)
     return RFLU_OK;
 }
 
+
+// ---- device-side stream gates ------------------------------------------------------------------------------------------
+// The leaf-wise schedule (driver.cpp: factor_leafwise) hands work between streams once per 64-column leaf.  A hipEvent record
+// + hipStreamWaitEvent pair costs the waiting AND the recording stream 40-50 us of pipeline bubble each (measured with
+// scripts/trace_timeline.sh) -- more than the launches the schedule removes -- so the per-leaf edges are ordinary one-wave
+// kernels on monotonically increasing 64-bit counters: gate_signal publishes `value` when the stream reaches it (everything
+// before it in the stream has completed and released its writes), gate_wait holds its stream until a counter reaches `value`.
+// A waiter that sees no progress for ~2 s raises the panel timeout flag (info[1] bit 0) and lets its stream go on.
+__global__ void gate_signal_kernel(unsigned long long* flag, unsigned long long value, long long* stamp)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamp) *stamp = (long long)wall_clock64();   // measurement builds only (RFLU_GATE_TRACE, scripts/gate_trace.py)
+}
+
+__global__ void gate_wait_kernel(const unsigned long long* flag, unsigned long long value, int64_t* info)
+{
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 200000000LL) {   // 100 MHz wall clock: 2 s
+            __hip_atomic_fetch_or((unsigned long long*)(info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+int launch_gate_signal(Handle* h, unsigned long long* flag, unsigned long long value, long long* stamp)
+{
+    hipLaunchKernelGGL(gate_signal_kernel, dim3(1), dim3(1), 0, h->stream, flag, value, stamp);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+int launch_gate_wait(Handle* h, const unsigned long long* flag, unsigned long long value)
+{
+    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(1), 0, h->stream, flag, value, h->info_dev);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
 }  // namespace rflu

@@ -52,6 +52,11 @@ struct Handle {
     // 224 of the 256 CUs so that the cooperative panel kernels of the critical path always find 32 free CUs
     hipStream_t ustreams[8] = {};     // ustreams[r]: CU mask leaving 32*r CUs to the critical path (r = 1..7)
     hipStream_t pstreams[8] = {};     // pstreams[r]: the complement -- exactly those 32*r CUs (critical path of the update-bound phase)
+    hipStream_t sstreams[2][8] = {};  // side streams of the leaf-wise schedule, same CU mask as ustreams[r]
+    unsigned long long* gates = nullptr;   // device: [0] critical path, [1] side stream 1, [2] side stream 2 (leaf counters)
+    unsigned long long* gate_ptr[3] = {};  // the three counters
+    unsigned long long gate_epoch = 0;     // counters only grow: leaf g of a factorization is gate_epoch + g + 1
+    long long* gate_stamps = nullptr;      // RFLU_GATE_TRACE: wall-clock stamps of the signals, [3][4096] (scripts/gate_trace.py)
     std::vector<hipEvent_t> events;   // reusable, timing disabled
     int last_path = RFLU_PATH_NONE;
     int num_cus = 256;
@@ -162,6 +167,8 @@ template <typename T>
 int launch_triu_base(Handle* h, int64_t nb, int64_t nrhs, const T* U, int64_t ldu, T* B, int64_t ldb);
 template <typename T>
 int launch_diag_inv(Handle* h, int64_t n, const T* L, int64_t ldl, T* Linv);
+template <typename T>
+int launch_trsm_inv64(Handle* h, int64_t n, int64_t nrhs, const T* Linv, T* B, int64_t ldb);   // one block, LDS-free
 // cooperative solve for few right-hand sides (trsv.hip): B <- U^-1 L^-1 B, interchanges already applied
 template <typename T>
 int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, T* B, int64_t ldb);
@@ -192,6 +199,8 @@ template <typename T>
 int launch_fill_uniform(Handle* h, T* A, int64_t m, int64_t n, int64_t ld, int row_major, uint64_t seed,
                         int64_t M_global, int64_t i0, int64_t j0, double diag_add);
 int launch_iota_ipiv(Handle* h, int64_t* ipiv, int64_t k0, int64_t n);
+int launch_gate_signal(Handle* h, unsigned long long* flag, unsigned long long value, long long* stamp = nullptr);   // laswp.hip: device-side stream gates
+int launch_gate_wait(Handle* h, const unsigned long long* flag, unsigned long long value);
 // butterfly.hip: A <- U' A V (column-major, in place) and x <- U' x (mode 0) / x <- V x (mode 1)
 template <typename T>
 int launch_butterfly_mul(Handle* h, int64_t n, T* A, int64_t lda, const T* uv);

@@ -208,6 +208,65 @@ int launch_trsm_fused(Handle* h, int64_t n, int64_t nrhs, const T* L, int64_t ld
     return RFLU_OK;
 }
 
+// B <- inv(L) * B for ONE diagonal block (n <= 64 rows) whose inverse is already known: no LDS at all, so the workgroups slip
+// onto CUs whose LDS the update GEMM has taken (the side streams of factor_leafwise run next to it; the 98 KB of
+// trsm_fused_kernel waited for a whole CU to drain, 180 us per launch).  One workgroup = 64 right-hand-side columns; every
+// wave loads the complete 64 x 64 B tile as MFMA B operands straight from global memory (16 lanes = 128 contiguous bytes of
+// a row), the barrier separates the last read of B from its first overwrite, wave w produces rows 16w .. 16w+15.
+template <typename T>
+__global__ void __launch_bounds__(256) trsm_inv64_kernel(int n, int64_t nrhs, const T* __restrict__ Linv, T* __restrict__ B,
+                                                         int64_t ldb)
+{
+    typedef typename MfmaT<T>::acc_t acc_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fk = lane >> 4;
+    const int64_t col0 = (int64_t)blockIdx.x * 64;
+    T b[16][4];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = kk * 4 + fk;
+            const int64_t col = col0 + t * 16 + fi;
+            b[kk][t] = (row < n && col < nrhs) ? B[(int64_t)row * ldb + col] : T(0);
+        }
+    T ai[16];
+    {
+        const T* Ip = Linv + (wave * 16 + fi) * NB + fk;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) ai[kk] = Ip[kk * 4];
+    }
+    __syncthreads();
+    acc_t x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = MfmaT<T>::run(ai[kk], b[kk][t], x[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + MfmaT<T>::crow(lane, r);
+            const int64_t col = col0 + t * 16 + fi;
+            if (row < n && col < nrhs) B[(int64_t)row * ldb + col] = x[t][r];
+        }
+}
+
+template <typename T>
+int launch_trsm_inv64(Handle* h, int64_t n, int64_t nrhs, const T* Linv, T* B, int64_t ldb)
+{
+    if (n <= 1 || nrhs <= 0) return RFLU_OK;
+    if (n > NB) { set_error("launch_trsm_inv64: %lld rows exceed %d", (long long)n, NB); return RFLU_ERR_ARG; }
+    ProfScope ps(h, RFLU_K_TRSM, (double)n * (double)n * (double)nrhs);
+    hipLaunchKernelGGL(trsm_inv64_kernel<T>, dim3((unsigned)((nrhs + 63) / 64)), dim3(256), 0, h->stream, (int)n, nrhs, Linv, B, ldb);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+template int launch_trsm_inv64<double>(Handle*, int64_t, int64_t, const double*, double*, int64_t);
+template int launch_trsm_inv64<float>(Handle*, int64_t, int64_t, const float*, float*, int64_t);
+
 template int launch_diag_inv<double>(Handle*, int64_t, const double*, int64_t, double*);
 template int launch_diag_inv<float>(Handle*, int64_t, const float*, int64_t, float*);
 template int launch_trsm_fused<double>(Handle*, int64_t, int64_t, const double*, int64_t, const double*, double*, int64_t);

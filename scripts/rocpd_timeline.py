@@ -7,9 +7,10 @@ rows = cur.execute("select name, start, end, queue_id, grid_x, workgroup_x from 
 tr = [i for i, r in enumerate(rows) if 'transpose' in r[0]]
 seg = rows[tr[2 * which]:tr[2 * which + 1] + 1]
 short = lambda n: re.sub(r"<.*", "", re.sub(r"\(.*", "", n.replace("void rflu::", "")))
-qP = seg[0][3]
+import collections
+qP = collections.Counter(r[3] for r in seg if 'panel_pivot' in r[0]).most_common(1)[0][0]   # the critical-path queue
 if len(sys.argv) > 5 and sys.argv[5] == 'U':   # the update queue instead: ordinals count its laswp kernels
-    qP = [r[3] for r in seg if r[3] != qP][0]
+    qP = collections.Counter(r[3] for r in seg if 'gemm_sub' in r[0] and r[3] != qP).most_common(1)[0][0]
 P = [r for r in seg if r[3] == qP]
 others = [r for r in seg if r[3] != qP]
 if len(sys.argv) > 5 and sys.argv[5] == 'U':

@@ -127,3 +127,19 @@ def test_n16384_float32_and_nopivot_variants(dtype, record_property):
         res = matvec_residual(A, F.factors, F.ipiv)
         assert res < 20 * n * np.finfo(np.float32).eps, res
         _free(A, F)
+
+
+@pytest.mark.parametrize("n,bs", [(2048, 128), (3000, 256), (4096, 512)])
+def test_leafwise_schedule_matches_default(n, bs, monkeypatch):
+    """The opt-in leaf-wise schedule (driver.cpp: factor_leafwise, RFLU_LEAFWISE=1) applies the same eliminations in the same
+    order as the default two-stream schedule: identical pivots, factors equal to rounding, residual below the 1e-12 bar."""
+    monkeypatch.delenv("RFLU_LEAFWISE", raising=False)
+    A, F = _factor(n, np.float64, True, bs)
+    monkeypatch.setenv("RFLU_LEAFWISE", "1")
+    _, G = _factor(n, np.float64, True, bs)
+    assert F.info == 0 and G.info == 0
+    assert rf.last_path() == "hip-lookahead"
+    assert torch.equal(F.ipiv, G.ipiv)
+    scale = float(F.factors.abs().max())
+    assert float((F.factors - G.factors).abs().max()) <= 1e-10 * scale
+    assert matvec_residual(A, G.factors, G.ipiv) < 1e-12

@@ -302,6 +302,14 @@ struct Fact {
     }
 };
 
+// workgroups of the cooperative leaf on `rows` rows (the CUs a schedule has to keep free for it)
+static int64_t panel_wgs(const Handle* h, int64_t rows, int pivot)
+{
+    rows = std::max<int64_t>(rows, 1);
+    const int64_t rpw = (pivot && h->panel_local > 0) ? panel_local_rows_per_wg(h, rows) : PANEL_THREADS;
+    return (rows + rpw - 1) / rpw;
+}
+
 static int get_event(Handle* h, size_t idx, hipEvent_t* ev)
 {
     while (h->events.size() <= idx) {
@@ -323,15 +331,6 @@ int get_ustream(Handle* h, int reserve, hipStream_t* out)
     if (reserve % 32 != 0 || r < 1 || r > 7) { set_error("CU reservation %d not in 32..224 step 32", reserve); return RFLU_ERR_ARG; }
     RFLU_TRY(get_masked_stream(h, &h->ustreams[r], r));
     *out = h->ustreams[r];
-    return RFLU_OK;
-}
-// side stream `which` (0/1) of the leaf-wise schedule: the same CUs as the update stream of that reservation
-static int get_sstream(Handle* h, int which, int reserve, hipStream_t* out)
-{
-    const int r = reserve / 32;
-    if (reserve % 32 != 0 || r < 1 || r > 7 || which < 0 || which > 1) { set_error("bad side stream request"); return RFLU_ERR_ARG; }
-    RFLU_TRY(get_masked_stream(h, &h->sstreams[which][r], r));
-    *out = h->sstreams[which][r];
     return RFLU_OK;
 }
 static int get_masked_stream(Handle* h, hipStream_t* slot, int r)
@@ -397,8 +396,10 @@ static double model_gemm_flops_per_us(int64_t K, int cus, size_t elem)
 // whole GPU.  The mask reserves ceil(panel workgroups / 32) * 32 CUs, chosen per block column.
 // Every block column receives the same operations in the same order as in the recursion; only independent pieces
 // overlap in time, so the factors are those of the one-stream path.
+// b_end < number of block columns: stop after block column b_end-1 (its update issued, block column b_end brought up to date on
+// P) and hand over to factor_leafwise; *U_last = the update stream of that block column.
 template <typename T>
-static int factor_lookahead(Fact<T>& f, int64_t W)
+static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U_last)
 {
     Handle* h = f.h;
     int min_reserve = 32;
@@ -424,7 +425,10 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
     // follows it, and is put back on every way out of this function.
     struct Restore { Handle* h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, h->stream};
     const hipStream_t userS = h->stream;
-    int64_t confine_rows = sizeof(T) == 8 ? 11264 : 1 << 30;   // panels at least this tall run confined (update-bound phase)
+    // Confining the critical path to the reserved CUs while the update is the bottleneck is worth 1.3 ms at N=16384 on its own,
+    // but it is a fourth queue next to {caller's stream, update stream, side stream of factor_leafwise}, and a factorization
+    // that uses four queues runs 25 % slower (DESIGN.md "queues"): off unless RFLU_CONFINE_ROWS asks for it.
+    int64_t confine_rows = (int64_t)1 << 40;
     if (const char* e = getenv("RFLU_CONFINE_ROWS")) confine_rows = atoll(e);
     auto move_P = [&](hipStream_t to, int64_t b) -> int {
         if (to == P) return RFLU_OK;
@@ -469,10 +473,10 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
         return update(P, pend.j0, pend.jb, pend.c0, n);
     };
 
-    for (int64_t b = 0; b < nblk; ++b) {
+    for (int64_t b = 0; b < std::min(nblk, b_end); ++b) {
         const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
         {
-            const int64_t g_b = (m - j0 + PANEL_THREADS - 1) / PANEL_THREADS;
+            const int64_t g_b = panel_wgs(h, m - j0, f.pivot);
             const int res_b = std::max<int>(min_reserve, int((std::max<int64_t>(g_b, 1) + 31) / 32 * 32));
             hipStream_t to = userS;
             if (b > 0 && prev_overlapped && m - j0 >= confine_rows && res_b == 32)   // taller panels: restB needs the whole GPU
@@ -486,7 +490,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
         RFLU_TRY(flush_pending());                                   // restB_{b-1}: whole GPU, after the panel
         // the panel that will run next to this block column's update is panel b+1
         const int64_t rows_next = m - je;
-        const int64_t g_next = (rows_next + PANEL_THREADS - 1) / PANEL_THREADS;
+        const int64_t g_next = panel_wgs(h, rows_next, f.pivot);
         const int reserve = std::max<int>(min_reserve, int((std::max<int64_t>(g_next, 1) + 31) / 32 * 32));
         if (reserve > std::min(max_reserve, 224)) {
             // the next panel needs (almost) the whole GPU: run this block column on one stream
@@ -575,6 +579,8 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
     f.sw_lo = 0;
     f.sw_hi = -1;
     f.gate = nullptr;
+    if (U_last) *U_last = Uprev;
+    if (b_end < nblk) return RFLU_OK;   // factor_leafwise goes on from here and joins at its end
     // join: P continues only after U has drained
     if (uend_prev >= 0) {
         RFLU_TRY(get_event(h, 4 * uend_prev + 3, &ev));
@@ -589,24 +595,26 @@ static int factor_lookahead(Fact<T>& f, int64_t W)
 // dependent launches between the leaves of every 512-column block (scripts/trace_timeline.sh) -- as much as a third of the
 // late, panel-bound phase.  Here every leaf g (64 columns) is applied right-looking, and only the 64 columns the NEXT leaf
 // needs stay on the critical-path stream:
-//   P  : leaf g -> {interchanges of leaf g on columns LA = [c0+64, c0+128), inverse of its diagonal block} -> evP[g]
-//        -> [wait: leaf g-1 applied to LA by a side stream] solve + update of LA (K = 64) -> leaf g+1 ...
-//   S1 : [wait evP[g]] leaf g applied to the rest of its own block column          -> evS1[g]
-//   S2 : [wait evP[g]; first leaf of a block: wait evU1[b-1]] ... to the next block column   -> evS2[g]
-//   U  : once per block column b, after its last leaf: [wait evS1, evS2] the deferred interchanges on the columns to the
+//   P  : leaf g -> [wait: leaf g-1 applied to LA = [c0+64, c0+128) by the side stream] {interchanges of leaf g on LA, inverse
+//        of its diagonal block} (gate P >= g; both gates ride on this launch) -> solve + update of LA (K = 64) -> leaf g+1 ...
+//   S  : [wait gate P >= g] leaf g applied to the rest of its own block column (gate S-in >= g) and to the next block column
+//        (first leaf of a block: after evU1[b-1]) (gate S-all >= g)
+//   U  : once per block column b, after its last leaf: [wait gate S-all] the deferred interchanges on the columns to the
 //        left, then block column b (K = W) applied to everything right of block column b+1 -- block column b+2 first
 //        (evU1[b]) -- exactly the update stream of factor_lookahead.
-// STATUS: opt-in (RFLU_LEAFWISE=1), parity-tested, NOT the default.  Measured at N=16384: 115-118 ms against 87 ms for
-// factor_lookahead (93 ms with rocprofv3 attached, which changes how the queues are served).  The critical-path stream's
-// kernels add up to ~225 us per leaf but it passes a leaf only every ~400 us (scripts/gate_trace.py): six dependent launches
-// per leaf on one queue, next to three queues whose heads are spinning gate kernels.  hipEvent edges instead of gates cost
-// 40-50 us of bubble per record/wait on the hot stream (136 ms); hipStreamWaitValue64/WriteValue64: 124 ms.  What the idea
-// needs is fewer launches on P (gates folded into the interchange kernel, solve + update fused) -- DESIGN.md "next".
-// S1/S2/U share the CU mask that keeps the panel's CUs free.  Every column receives the same eliminations in the same order
+// Queues: the critical path stays on the caller's stream and there is ONE side stream (the next block column's part of the first
+// leaf of a block waits for evU1 between two gates of its own).  An earlier version with two side streams and the critical path
+// on a third, CU-confined stream ran at 115-118 ms for N=16384 instead of 88: a factorization that uses four or more queues
+// is served 25-30 % slower whatever they do (the same happened to factor_lookahead with one extra stream; idle streams that
+// are never used do not count; rocprofv3 hides the effect -- DESIGN.md "queues").  hipEvent edges per leaf cost 40-50 us of
+// bubble per record/wait on the hot stream, hipStreamWaitValue64/WriteValue64 were slower still: hence the device-side gates.
+// Measured (Float64, ms): N=4096 13.6 -> 12.0, N=8192 29.7 -> 26.8, N=12288 51.6 -> 49.6; N=16384 whole matrix 88.3, from the
+// first panel of <= 8192 rows on (after factor_lookahead) 84.8 vs 86.1.
+// S and U share the CU mask that keeps the panel's CUs free.  Every column receives the same eliminations in the same order
 // as in reckernel! (src/lu.jl:189-263); inside a block column the Schur complement is accumulated 64 pivots at a time instead
 // of in the recursion's growing chunks, so factors agree with the one-stream path to rounding, pivots exactly.
 template <typename T>
-static int factor_leafwise(Fact<T>& f, int64_t W)
+static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U_before)
 {
     Handle* h = f.h;
     const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
@@ -615,12 +623,17 @@ static int factor_leafwise(Fact<T>& f, int64_t W)
     struct Restore { Handle* h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, userS};
     hipStream_t P = userS;
     const int64_t nblk = (mn + W - 1) / W, nleaf = (mn + NB - 1) / NB;
-    const size_t EB = 3 * (size_t)nleaf;   // events: leaf g -> 3g (evP), 3g+1 (evS1), 3g+2 (evS2); block b -> EB+2b (evU1), EB+2b+1 (evUend)
-    // the panel's workgroups must not share CUs with the side streams' kernels: the critical path lives on the reserved CUs
-    int64_t confine_rows = 0;
+    // events as in factor_lookahead: block b -> 4b+2 (evU1), 4b+3 (evUend); stream moves of this function from EX on
+    const size_t EX = 4 * (size_t)nblk + 8;
+    auto evU1 = [](int64_t b) { return 4 * (size_t)b + 2; };
+    auto evUend = [](int64_t b) { return 4 * (size_t)b + 3; };
+    // RFLU_CONFINE_ROWS: panels at least this tall run on the stream confined to the reserved CUs (default: never -- the
+    // critical path stays on the caller's stream: three active queues in all, see the header comment)
+    const bool fold = !(getenv("RFLU_GATE_FOLD") && atoi(getenv("RFLU_GATE_FOLD")) == 0) && !getenv("RFLU_GATE_TRACE");
+    int64_t confine_rows = (int64_t)1 << 40;
     if (const char* e = getenv("RFLU_CONFINE_ROWS")) confine_rows = atoll(e);
     auto reserve_for = [&](int64_t rows) {
-        const int64_t g = (std::max<int64_t>(rows, 1) + PANEL_THREADS - 1) / PANEL_THREADS;
+        const int64_t g = panel_wgs(h, rows, f.pivot);
         return std::max<int>(32, int((g + 31) / 32 * 32));
     };
     auto wait_on = [&](hipStream_t st, size_t idx) -> int {
@@ -661,28 +674,31 @@ static int factor_leafwise(Fact<T>& f, int64_t W)
         h->stream = saved;
         return rc;
     };
-    hipStream_t Uprev = nullptr, S1prev = nullptr, S2prev = nullptr;
+    hipStream_t Uprev = U_before, Sprev = nullptr;   // U_before: the update stream of block b_begin-1 (factor_lookahead)
     const unsigned long long gbase = h->gate_epoch;
     h->gate_epoch += (unsigned long long)nleaf + 2;
     auto val = [&](int64_t g) { return gbase + (unsigned long long)g + 1; };
+    const int64_t gfirst = b_begin * W / NB;   // the leaves before it were factored (and applied everywhere) by factor_lookahead
     if (getenv("RFLU_GATE_TRACE") && !h->gate_stamps) {
         RFLU_HIP(hipMalloc((void**)&h->gate_stamps, 3 * 4096 * sizeof(long long)));
         RFLU_HIP(hipMemset(h->gate_stamps, 0, 3 * 4096 * sizeof(long long)));
     }
     auto stamp = [&](int which, int64_t g) -> long long* { return (h->gate_stamps && g < 4096) ? h->gate_stamps + which * 4096 + g : nullptr; };
-    for (int64_t b = 0; b < nblk; ++b) {
+    for (int64_t b = b_begin; b < nblk; ++b) {
         const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
         const int64_t bend = std::min(j0 + W, n), wend = std::min(j0 + 2 * W, n);
         const int res = reserve_for(m - j0);
-        hipStream_t S1, S2;
-        RFLU_TRY(get_sstream(h, 0, res, &S1));
-        RFLU_TRY(get_sstream(h, 1, res, &S2));
+        // The side stream is the update stream of the 64-CU reservation: it keeps away from the panel's 32 CUs like U does,
+        // and a taller matrix has already used it for its first block columns -- no fourth queue (see the header comment).
+        if (res != 32) { set_error("factor_leafwise: panel of %lld rows needs more than 32 CUs", (long long)(m - j0)); return RFLU_ERR_ARG; }
+        hipStream_t S;
+        RFLU_TRY(get_ustream(h, 64, &S));
         {   // the critical path runs on the reserved CUs while the update stream is the bottleneck (see get_pstream)
             hipStream_t to = userS;
             if (m - j0 >= confine_rows && res == 32) RFLU_TRY(get_pstream(h, res, &to));
             if (to != P) {
-                RFLU_TRY(record_on(P, EB + 2 * (size_t)nblk + (size_t)b));
-                RFLU_TRY(wait_on(to, EB + 2 * (size_t)nblk + (size_t)b));
+                RFLU_TRY(record_on(P, EX + (size_t)b));
+                RFLU_TRY(wait_on(to, EX + (size_t)b));
                 P = to;
                 h->stream = to;
             }
@@ -692,53 +708,61 @@ static int factor_leafwise(Fact<T>& f, int64_t W)
             const int64_t g = g0 + i, c0 = j0 + i * NB, w = std::min<int64_t>(NB, je - c0);
             RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, f.ipiv, f.pivot));
             const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);
-            if (la1 > la0 && g > 0) {   // leaf g-1 reached LA through a side stream: its own block's, or the next block's
-                const int64_t bendp = std::min(((c0 - NB) / W + 1) * W, n);
-                RFLU_TRY(launch_gate_wait(h, h->gate_ptr[la0 < bendp ? 1 : 2], val(g - 1)));
+            const unsigned long long* wflag = nullptr;   // leaf g-1 reached LA through the side stream: in its own block's part, or the next block's
+            if (la1 > la0 && g > gfirst) wflag = h->gate_ptr[la0 < std::min(((c0 - NB) / W + 1) * W, n) ? 1 : 2];
+            if (f.pivot && fold) {   // both gates ride on the interchange launch: two launches less per leaf on this stream
+                LaswpGate gt;
+                gt.wait_flag = wflag;
+                gt.wait_val = wflag ? val(g - 1) : 0;
+                gt.signal_flag = h->gate_ptr[0];
+                gt.signal_val = val(g);
+                gt.signal_cnt = reinterpret_cast<unsigned*>(h->gates + 4);
+                gt.info = h->info_dev;
+                RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0), gt));
+            } else {
+                if (wflag) RFLU_TRY(launch_gate_wait(h, wflag, val(g - 1)));
+                if (f.pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0)));
+                else RFLU_TRY(launch_diag_inv<T>(h, w, R + c0 * ld + c0, ld, f.linv_at(c0)));
+                RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g), stamp(0, g)));
             }
-            if (f.pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0)));
-            else RFLU_TRY(launch_diag_inv<T>(h, w, R + c0 * ld + c0, ld, f.linv_at(c0)));
-            RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g), stamp(0, g)));
             RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
-            // ---- side stream 1: the rest of this block column ----
-            h->stream = S1;
+            // ---- side stream: leaf g on the rest of this block column and on the next one ----
+            h->stream = S;
             int rc = launch_gate_wait(h, h->gate_ptr[0], val(g));
-            if (rc == RFLU_OK && i == 0 && b > 0) {   // these columns were last written by the previous block's S2; S1 may be a new stream
-                rc = launch_gate_wait(h, h->gate_ptr[2], val(g - 1));
-                if (rc == RFLU_OK && S1 != S1prev) rc = launch_gate_wait(h, h->gate_ptr[1], val(g - 1));
-            }
-            if (rc == RFLU_OK) rc = apply_leaf(S1, c0, w, la1, bend, true);
-            h->stream = S1;
-            if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g), stamp(1, g));
-            // ---- side stream 2: the next block column ----
-            h->stream = S2;
-            if (rc == RFLU_OK) rc = launch_gate_wait(h, h->gate_ptr[0], val(g));
-            if (rc == RFLU_OK && i == 0 && b > 0) {   // block column b+1 holds U(b-1)'s update; S2 may be a new stream
+            if (rc == RFLU_OK && i == 0 && S != Sprev && g > gfirst) rc = launch_gate_wait(h, h->gate_ptr[2], val(g - 1));
+            if (i == 0 && b > 0) {
+                // the next block column holds U(b-1)'s update only after evU1[b-1]; the critical path needs this block
+                // column's part first, so the leaf is applied in two pieces with a gate of its own in between
+                if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, la1, bend, true);
+                h->stream = S;
+                if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g), stamp(1, g));
                 hipEvent_t e;
-                rc = get_event(h, EB + 2 * (size_t)(b - 1), &e);
-                if (rc == RFLU_OK && hipStreamWaitEvent(S2, e, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); rc = RFLU_ERR_HIP; }
-                if (rc == RFLU_OK && S2 != S2prev) rc = launch_gate_wait(h, h->gate_ptr[2], val(g - 1));
+                if (rc == RFLU_OK) rc = get_event(h, evU1(b - 1), &e);
+                if (rc == RFLU_OK && hipStreamWaitEvent(S, e, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); rc = RFLU_ERR_HIP; }
+                if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, std::max(la1, bend), wend, true);
+                h->stream = S;
+                if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[2], val(g), stamp(2, g));
+            } else {
+                if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, la1, wend, true);
+                h->stream = S;
+                if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g), stamp(1, g));
+                if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[2], val(g), stamp(2, g));
             }
-            if (rc == RFLU_OK) rc = apply_leaf(S2, c0, w, std::max(la1, bend), wend, true);
-            h->stream = S2;
-            if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[2], val(g), stamp(2, g));
             h->stream = P;
             RFLU_TRY(rc);
         }
-        S1prev = S1;
-        S2prev = S2;
+        Sprev = S;
         // ---- U(b): everything right of block column b+1, and the interchanges nobody needed until now ----
         hipStream_t U;
         RFLU_TRY(get_ustream(h, reserve_for(m - je), &U));
         const int64_t glast = g0 + nl - 1;
         {
             h->stream = U;
-            int rc = launch_gate_wait(h, h->gate_ptr[1], val(glast));
-            if (rc == RFLU_OK) rc = launch_gate_wait(h, h->gate_ptr[2], val(glast));
+            const int rc = launch_gate_wait(h, h->gate_ptr[2], val(glast));
             h->stream = P;
             RFLU_TRY(rc);
         }
-        if (Uprev && Uprev != U) RFLU_TRY(wait_on(U, EB + 2 * (size_t)(b - 1) + 1));
+        if (Uprev && Uprev != U) RFLU_TRY(wait_on(U, evUend(b - 1)));
         if (f.pivot) {
             hipStream_t saved = h->stream;
             h->stream = U;
@@ -751,18 +775,18 @@ static int factor_leafwise(Fact<T>& f, int64_t W)
         }
         const int64_t p1e = std::min(wend + W, n);
         RFLU_TRY(update(U, j0, jb, wend, p1e));
-        RFLU_TRY(record_on(U, EB + 2 * (size_t)b));
+        RFLU_TRY(record_on(U, evU1(b)));
         RFLU_TRY(update(U, j0, jb, p1e, n));
-        RFLU_TRY(record_on(U, EB + 2 * (size_t)b + 1));
+        RFLU_TRY(record_on(U, evUend(b)));
         Uprev = U;
     }
     if (P != userS) {
-        RFLU_TRY(record_on(P, EB + 3 * (size_t)nblk));
-        RFLU_TRY(wait_on(userS, EB + 3 * (size_t)nblk));
+        RFLU_TRY(record_on(P, EX + (size_t)nblk));
+        RFLU_TRY(wait_on(userS, EX + (size_t)nblk));
         P = userS;
         h->stream = userS;
     }
-    RFLU_TRY(wait_on(userS, EB + 2 * (size_t)(nblk - 1) + 1));
+    RFLU_TRY(wait_on(userS, evUend(nblk - 1)));
     return RFLU_OK;
 }
 
@@ -790,19 +814,33 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     Fact<T> f{h, R, ld, m, n, ipiv, pivot};
     bool fat_tail_done = false;
     if (blocksize == 0)  // measured on MI355X (bench.py --blocksize sweep): the knee moves right with the matrix size
-        blocksize = mn < 1024 ? -1 : (mn <= 8192 ? 128 : (mn <= 12288 ? 256 : (mn <= 16384 ? 512 : (mn <= 24576 ? 1024 : 2048))));
+        blocksize = mn < 1024 ? -1 : (mn <= 12288 ? 256 : (mn <= 16384 ? 512 : (mn <= 24576 ? 1024 : 2048)));
     if (blocksize < 0 || blocksize >= mn) {
         h->last_path = RFLU_PATH_HIP_RECURSIVE;
         RFLU_TRY(f.rec(0, mn));
     } else if (!h->prof && h->num_cus == 256) {   // the CU reservation of the two-stream schedule is laid out for 8 x 32 CUs
         h->last_path = RFLU_PATH_HIP_LOOKAHEAD;
-        // RFLU_LEAFWISE=1: the experimental leaf-wise schedule (correct and parity-tested; measured slower, see factor_leafwise)
+        // tall block columns (update-bound): factor_lookahead; from the first panel of at most lw_rows rows on: factor_leafwise.
+        // RFLU_LEAFWISE=0 keeps the lookahead schedule to the end.
         const char* lw = getenv("RFLU_LEAFWISE");
-        const int leafwise = lw ? atoi(lw) : 0;
+        const int leafwise = lw ? atoi(lw) : 1;
         const int64_t Wb = round_up(blocksize, NB);
         const auto t_enq0 = std::chrono::steady_clock::now();
-        if (leafwise && Wb >= 2 * NB && (m + PANEL_THREADS - 1) / PANEL_THREADS <= 64) RFLU_TRY(factor_leafwise<T>(f, Wb));
-        else RFLU_TRY(factor_lookahead<T>(f, Wb));
+        const int64_t nblk = (mn + Wb - 1) / Wb;
+        int64_t b_switch = nblk;   // first block column of the leaf-wise part
+        // (block columns wider than 512 make the side stream's per-leaf window -- up to 2 W columns at K = 64 -- too much work to
+        //  finish within one leaf: N=32768 at W=2048 is 0.8 % (Float64) / 5 % (Float32) slower leaf-wise, so those stay as they were)
+        if (leafwise && Wb >= 2 * NB && Wb <= 512) {
+            // Float64: panels at most this tall are the bottleneck of their block column (N=16384: 84.8 ms at 7168-8192, 85.4 at
+            // 9216, 88.3 for the whole matrix); Float32's faster GEMM leaves the panel the bottleneck everywhere (61.7 vs 64.5 ms)
+            int64_t lw_rows = sizeof(T) == 8 ? 8192 : 16384;   // 16384 rows = 32 workgroups: the most the 32 reserved CUs take
+            if (const char* e = getenv("RFLU_LEAFWISE_ROWS")) lw_rows = atoll(e);
+            lw_rows = std::min<int64_t>(lw_rows, 32 * (int64_t)PANEL_THREADS);
+            b_switch = m <= lw_rows ? 0 : std::min(nblk, (m - lw_rows + Wb - 1) / Wb);
+        }
+        hipStream_t U_last = nullptr;
+        if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last));
+        if (b_switch < nblk) RFLU_TRY(factor_leafwise<T>(f, Wb, b_switch, U_last));
         if (getenv("RFLU_TIME_ENQUEUE"))
             fprintf(stderr, "[rflu] host enqueue time %.2f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count());
@@ -1010,9 +1048,6 @@ int rflu_destroy(rflu_handle_t handle)
         if (us) (void)hipStreamDestroy(us);
     for (hipStream_t ps : h->pstreams)
         if (ps) (void)hipStreamDestroy(ps);
-    for (auto& row : h->sstreams)
-        for (hipStream_t ss : row)
-            if (ss) (void)hipStreamDestroy(ss);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     for (auto& r : h->async_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : h->async_pool) (void)hipEventDestroy(e);

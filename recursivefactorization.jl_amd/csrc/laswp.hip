@@ -16,22 +16,12 @@ constexpr int LW_COLS = 16;           // columns per workgroup: 16 lanes x 8 byt
 constexpr int LW_RSUB = 64 / LW_COLS; // row slots per wave (a wave covers 4 rows x 16 columns per access)
 constexpr int LW_ROWS_PER_THREAD = (2 * NB) / (4 * LW_RSUB);  // 4 waves x 4 row slots share the <=128 moves of a chunk
 
-// inv_nb > 0: extra workgroups (the last inv_cnt) invert the leaves' 64x64 diagonal blocks for the fused TRSMs that follow
-// (trsm.hip) -- they ride along with the leaf's interchange launch instead of costing a dependent launch of their own.
-// A third column range [c2, c2+ncolsC) receives only the chunks after the first: for a pair leaf (panel.hip) these are
-// leaf A's own columns, which still need leaf B's interchanges.
-// Geometry: narrow column strips (16 columns) give 4x the workgroups of a 64-column strip -- a full-width launch at N=16384
-// is ~1000 workgroups instead of 248 (less than one per CU), so four times as many row loads are in flight per dependent
-// {move list -> rows -> barrier -> stores} round of a chunk.
 template <typename T>
-__global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA,
-                                                    int64_t c1, int64_t ncolsB, int64_t c2, int64_t ncolsC,
-                                                    const int* __restrict__ pm_cnt, const int* __restrict__ pm_dst,
-                                                    const int* __restrict__ pm_src, int chunk0, int chunk1, int inv_nb,
-                                                    int inv_cnt, const T* inv_L, T* inv_out)
+__device__ __forceinline__ void laswp_body(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1,
+                                           int64_t ncolsB, int64_t c2, int64_t ncolsC, const int* __restrict__ pm_cnt,
+                                           const int* __restrict__ pm_dst, const int* __restrict__ pm_src, int chunk0,
+                                           int chunk1, int inv_nb, int inv_cnt, const T* inv_L, T* inv_out, T* sL, T* sX)
 {
-    __shared__ T sL[NB * NB];
-    __shared__ T sX[NB * NB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t blocksA = (ncolsA + LW_COLS - 1) / LW_COLS;
@@ -88,52 +78,94 @@ __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t l
     }
 }
 
+// inv_nb > 0: extra workgroups (the last inv_cnt) invert the leaves' 64x64 diagonal blocks for the fused TRSMs that follow
+// (trsm.hip) -- they ride along with the leaf's interchange launch instead of costing a dependent launch of their own.
+// A third column range [c2, c2+ncolsC) receives only the chunks after the first: for a pair leaf (panel.hip) these are
+// leaf A's own columns, which still need leaf B's interchanges.
+// Geometry: narrow column strips (16 columns) give 4x the workgroups of a 64-column strip -- a full-width launch at N=16384
+// is ~1000 workgroups instead of 248 (less than one per CU), so four times as many row loads are in flight per dependent
+// {move list -> rows -> barrier -> stores} round of a chunk.
+template <typename T>
+__global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA,
+                                                    int64_t c1, int64_t ncolsB, int64_t c2, int64_t ncolsC,
+                                                    const int* __restrict__ pm_cnt, const int* __restrict__ pm_dst,
+                                                    const int* __restrict__ pm_src, int chunk0, int chunk1, int inv_nb,
+                                                    int inv_cnt, const T* inv_L, T* inv_out, LaswpGate gate)
+{
+    __shared__ T sL[NB * NB];
+    __shared__ T sX[NB * NB];
+    if (gate.wait_flag) {   // folded stream gate (factor_leafwise): hold until another stream has passed `wait_val`
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(gate.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gate.wait_val) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > 200000000LL) {
+                    __hip_atomic_fetch_or((unsigned long long*)(gate.info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    laswp_body<T>(R, ld, c0, ncolsA, c1, ncolsB, c2, ncolsC, pm_cnt, pm_dst, pm_src, chunk0, chunk1, inv_nb, inv_cnt, inv_L,
+                  inv_out, sL, sX);
+    if (gate.signal_flag) {   // the last workgroup to get here publishes `signal_val` (the counter wraps back to zero)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicInc(gate.signal_cnt, gridDim.x - 1) == gridDim.x - 1)
+                __hip_atomic_store(gate.signal_flag, gate.signal_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // Apply chunks [chunk0, chunk1) to the column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB), and chunks [chunk0+1, chunk1) to
 // [c2, c2+ncolsC); optionally invert inv_cnt consecutive inv_nb x inv_nb unit lower diagonal blocks starting at inv_L
 // (leading dimension ld) into inv_out in the same launch.
 template <typename T>
 int launch_laswp3(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t c2,
                   int64_t ncolsC, int64_t chunk0, int64_t chunk1, int64_t inv_nb, int64_t inv_cnt, const T* inv_L,
-                  T* inv_out)
+                  T* inv_out, LaswpGate gate)
 {
     if (ncolsA < 0) ncolsA = 0;
     if (ncolsB < 0) ncolsB = 0;
     if (ncolsC < 0 || chunk1 - chunk0 < 2) ncolsC = 0;
     const bool swaps = chunk1 > chunk0 && ncolsA + ncolsB + ncolsC > 0;
     if (inv_nb <= 0) inv_cnt = 0;
-    if (!swaps && inv_cnt <= 0) return RFLU_OK;
+    if (!swaps && inv_cnt <= 0 && !gate.wait_flag && !gate.signal_flag) return RFLU_OK;
     if (!swaps) { ncolsA = ncolsB = ncolsC = 0; }
-    const int64_t blocks = (ncolsA + LW_COLS - 1) / LW_COLS + (ncolsB + LW_COLS - 1) / LW_COLS +
-                           (ncolsC + LW_COLS - 1) / LW_COLS + inv_cnt;
+    int64_t blocks = (ncolsA + LW_COLS - 1) / LW_COLS + (ncolsB + LW_COLS - 1) / LW_COLS +
+                     (ncolsC + LW_COLS - 1) / LW_COLS + inv_cnt;
+    if (blocks == 0) blocks = 1;   // gates only: one idle workgroup (beyond every range, inv_cnt == 0)
     ProfScope ps(h, RFLU_K_LASWP, 4.0 * sizeof(T) * (double)NB *
                                       ((double)(ncolsA + ncolsB) * (double)(chunk1 - chunk0) +
                                        (double)ncolsC * (double)(chunk1 - chunk0 - 1)));
     hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, h->stream, R, ld, c0, ncolsA, c1, ncolsB, c2,
                        ncolsC, h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk0, (int)chunk1, (int)inv_nb, (int)inv_cnt, inv_L,
-                       inv_out);
+                       inv_out, gate);
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }
 
 template <typename T>
 int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t chunk0,
-                  int64_t chunk1, int64_t inv_nb, const T* inv_L, T* inv_out)
+                  int64_t chunk1, int64_t inv_nb, const T* inv_L, T* inv_out, LaswpGate gate)
 {
-    return launch_laswp3<T>(h, R, ld, c0, ncolsA, c1, ncolsB, 0, 0, chunk0, chunk1, inv_nb, 1, inv_L, inv_out);
+    return launch_laswp3<T>(h, R, ld, c0, ncolsA, c1, ncolsB, 0, 0, chunk0, chunk1, inv_nb, 1, inv_L, inv_out, gate);
 }
 
 template <typename T>
 int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t chunk0, int64_t chunk1)
 {
-    return launch_laswp2<T>(h, R, ld, c0, ncols, 0, 0, chunk0, chunk1, 0, nullptr, nullptr);
+    return launch_laswp2<T>(h, R, ld, c0, ncols, 0, 0, chunk0, chunk1, 0, nullptr, nullptr, LaswpGate{});
 }
 
 template int launch_laswp<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t);
 template int launch_laswp<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t);
-template int launch_laswp3<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, double*);
-template int launch_laswp3<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const float*, float*);
-template int launch_laswp2<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, double*);
-template int launch_laswp2<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const float*, float*);
+template int launch_laswp3<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, double*, LaswpGate);
+template int launch_laswp3<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const float*, float*, LaswpGate);
+template int launch_laswp2<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, double*, LaswpGate);
+template int launch_laswp2<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const float*, float*, LaswpGate);
 
 // ---- tiled transpose: out[r][c] = in[c][r]; "rows_out x cols_out" is the shape of `out` seen as row-major ------------
 // Used for column-major <-> R layout: a column-major m x n matrix (lda) IS a row-major n x m matrix (ld = lda).

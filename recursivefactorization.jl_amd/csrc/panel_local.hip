@@ -541,6 +541,24 @@ __global__ void __launch_bounds__(PW * 64 + 64) panel_pivot_local_kernel(LocalAr
     }
 }
 
+// Rows per workgroup of a pivoted leaf of `rows` rows.  The fewer row waves a workgroup has, the cheaper its per-column
+// argmax / barrier: 2.44 (64 rows), 2.55 (128), 2.72 (256) and 2.95 us per column (512) alone on the GPU
+// (scripts/panel_bench.py).  One polling wave reads at most 64 headers and the lookahead schedule keeps 32 or 64 CUs free, so a
+// panel takes the smallest workgroup that keeps it at <= RFLU_PANEL_MAXG workgroups; RFLU_PANEL_PW=1|2|4|8 sets a floor.
+#ifndef RFLU_PANEL_F32_TU
+int panel_local_rows_per_wg(const Handle* h, int64_t rows)
+{
+    static const int force_pw = [] { const char* e = getenv("RFLU_PANEL_PW"); return e ? atoi(e) : 0; }();
+    static const int max_g = [] { const char* e = getenv("RFLU_PANEL_MAXG"); return e ? atoi(e) : 32; }();
+    if (h->coop_launch) return 512;
+    const int floor_pw = force_pw > 0 ? force_pw : 1;
+    if (floor_pw <= 1 && (rows + 63) / 64 <= max_g) return 64;
+    if (floor_pw <= 2 && (rows + 127) / 128 <= max_g) return 128;
+    if (floor_pw <= 4 && (rows + 255) / 256 <= 32) return 256;
+    return 512;
+}
+#endif
+
 // Launch the leaf on the blocks b with b % stride == sel of a grid of G*stride workgroups.  local != 0: plain-store
 // records (all participants must share an XCD: stride 8); local == 0: sc1 records, any placement.
 template <typename T>
@@ -551,18 +569,32 @@ int launch_panel_local(Handle* h, const PanelArgs<T>& p0, int stride, int sel, i
     la.stride = stride;
     la.sel = sel;
     la.want_xcc = want_xcc;
-    // 256-row workgroups (one row wave per SIMD) while they still number at most 32 -- the CUs the lookahead schedule keeps
-    // free for the panel; taller panels use 512-row workgroups.  RFLU_PANEL_PW=8 forces the latter.
-    static const int force_pw = [] { const char* e = getenv("RFLU_PANEL_PW"); return e ? atoi(e) : 0; }();
     const int64_t rows = (int64_t)p0.m - p0.r0;
-    const int g4 = (int)((rows + 255) / 256);
-    const bool pw4 = force_pw == 4 || (force_pw == 0 && g4 <= 32 && !h->coop_launch);
-    if (pw4) la.p.G = g4;
+    const int rpw = local ? (((rows + 255) / 256 <= 32 && !h->coop_launch) ? 256 : 512) : panel_local_rows_per_wg(h, rows);
+    la.p.G = (int)((rows + rpw - 1) / rpw);
+    const bool pw4 = rpw == 256;
     const dim3 grid((unsigned)(la.p.G * stride));
     if (h->coop_launch && stride == 1) {   // launch-time residency check by the runtime (opt-in: +15-19 us per launch)
         void* kargs[] = {&la};
         RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 8>), grid,
                                             dim3(8 * 64 + 64), kargs, 0, h->stream));
+        return RFLU_OK;
+    }
+    if (rpw <= 128) {
+        // LDS ballast: a two- or three-wave workgroup fits next to the update GEMM's workgroups on a shared CU and is then
+        // slowed by them (N=4096: 13.3 ms without, 12.7 ms with); asking for more LDS than a CU with a GEMM workgroup (70 KB
+        // each) has left sends it to an empty CU -- one of those the update stream's mask keeps free.
+        static const int ballast = [] { const char* e = getenv("RFLU_PANEL_BALLAST"); return e ? atoi(e) : 96 * 1024; }();
+        bool& attr_set = h->panel_attr_set[sizeof(T) == 8 ? 0 : 1][rpw == 64 ? 0 : 1];   // per handle = per device
+        const void* fn = rpw == 64 ? reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 1>)
+                                   : reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 2>);
+        if (!attr_set && ballast > 0) {
+            RFLU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ballast));
+            attr_set = true;
+        }
+        if (rpw == 64) hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 1>), grid, dim3(1 * 64 + 64), (size_t)ballast, h->stream, la);
+        else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 2>), grid, dim3(2 * 64 + 64), (size_t)ballast, h->stream, la);
+        RFLU_HIP(hipGetLastError());
         return RFLU_OK;
     }
     if (pw4) {

@@ -52,7 +52,7 @@ struct Handle {
     // 224 of the 256 CUs so that the cooperative panel kernels of the critical path always find 32 free CUs
     hipStream_t ustreams[8] = {};     // ustreams[r]: CU mask leaving 32*r CUs to the critical path (r = 1..7)
     hipStream_t pstreams[8] = {};     // pstreams[r]: the complement -- exactly those 32*r CUs (critical path of the update-bound phase)
-    hipStream_t sstreams[2][8] = {};  // side streams of the leaf-wise schedule, same CU mask as ustreams[r]
+    bool panel_attr_set[2][2] = {};        // [Float64|Float32][64|128 rows]: dynamic-LDS attribute of the small-workgroup leaves
     unsigned long long* gates = nullptr;   // device: [0] critical path, [1] side stream 1, [2] side stream 2 (leaf counters)
     unsigned long long* gate_ptr[3] = {};  // the three counters
     unsigned long long gate_epoch = 0;     // counters only grow: leaf g of a factorization is gate_epoch + g + 1
@@ -154,6 +154,7 @@ int ensure_bookkeeping(Handle* h, int64_t rows);
 int ensure_buffer(void** ptr, size_t* cap, size_t need);  // grow-only device buffer (hipFree + hipMalloc)
 
 // ---- kernel launchers (each returns an rflu_status); all pointers are device pointers in R layout -----------------------
+int panel_local_rows_per_wg(const Handle* h, int64_t rows);   // panel_local.hip: rows per workgroup of a pivoted leaf
 int launch_heat(Handle* h, int cus, double usec);   // gemm.hip: clock keeper
 template <typename T>
 int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C,
@@ -172,16 +173,27 @@ int launch_trsm_inv64(Handle* h, int64_t n, int64_t nrhs, const T* Linv, T* B, i
 // cooperative solve for few right-hand sides (trsv.hip): B <- U^-1 L^-1 B, interchanges already applied
 template <typename T>
 int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, T* B, int64_t ldb);
+// stream gates folded into an interchange launch (laswp.hip; used by factor_leafwise): hold the launch until *wait_flag >=
+// wait_val, and let its last workgroup publish signal_val (signal_cnt: a zero-initialised counter that wraps by itself)
+struct LaswpGate {
+    const unsigned long long* wait_flag = nullptr;
+    unsigned long long wait_val = 0;
+    unsigned long long* signal_flag = nullptr;
+    unsigned long long signal_val = 0;
+    unsigned* signal_cnt = nullptr;
+    int64_t* info = nullptr;   // timeout flag (info[1] bit 0)
+};
 template <typename T>
 int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t chunk0, int64_t chunk1);
 // apply chunks [chunk0, chunk1) to two column ranges at once: [c0, c0+ncolsA) and [c1, c1+ncolsB)
 template <typename T>
 int launch_laswp3(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t c2,
                   int64_t ncolsC, int64_t chunk0, int64_t chunk1, int64_t inv_nb, int64_t inv_cnt, const T* inv_L,
-                  T* inv_out);
+                  T* inv_out, LaswpGate gate = LaswpGate{});
 template <typename T>
 int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t chunk0,
-                  int64_t chunk1, int64_t inv_nb = 0, const T* inv_L = nullptr, T* inv_out = nullptr);
+                  int64_t chunk1, int64_t inv_nb = 0, const T* inv_L = nullptr, T* inv_out = nullptr,
+                  LaswpGate gate = LaswpGate{});
 // fold the interchanges ipiv[k0..k1) (k0 a multiple of NB) into per-chunk row-move lists
 int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, int64_t m);
 size_t panel_scratch_bytes();

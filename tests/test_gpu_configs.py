@@ -129,13 +129,14 @@ def test_n16384_float32_and_nopivot_variants(dtype, record_property):
         _free(A, F)
 
 
-@pytest.mark.parametrize("n,bs", [(2048, 128), (3000, 256), (4096, 512)])
+@pytest.mark.parametrize("n,bs", [(2048, 128), (3000, 256), (4096, 512), (12288, 512)])
 def test_leafwise_schedule_matches_default(n, bs, monkeypatch):
-    """The opt-in leaf-wise schedule (driver.cpp: factor_leafwise, RFLU_LEAFWISE=1) applies the same eliminations in the same
-    order as the default two-stream schedule: identical pivots, factors equal to rounding, residual below the 1e-12 bar."""
-    monkeypatch.delenv("RFLU_LEAFWISE", raising=False)
+    """The leaf-wise schedule (driver.cpp: factor_leafwise, the default for panels of at most 8192 rows) applies the same
+    eliminations in the same order as the block-column lookahead schedule it replaces (RFLU_LEAFWISE=0): identical pivots,
+    factors equal to rounding, residual below the 1e-12 bar."""
+    monkeypatch.setenv("RFLU_LEAFWISE", "0")
     A, F = _factor(n, np.float64, True, bs)
-    monkeypatch.setenv("RFLU_LEAFWISE", "1")
+    monkeypatch.delenv("RFLU_LEAFWISE", raising=False)
     _, G = _factor(n, np.float64, True, bs)
     assert F.info == 0 and G.info == 0
     assert rf.last_path() == "hip-lookahead"

@@ -52,8 +52,10 @@ enum rflu_kclass {
     RFLU_K_PANEL = 3,     /* _generic_lufact!   (src/lu.jl:290-338) cooperative leaf panel */
     RFLU_K_TRANSPOSE = 4, /* column-major <-> internal row-major layout change at the boundary */
     RFLU_K_MISC = 5,      /* pivot bookkeeping, fills */
-    RFLU_K_GEMM_SMALL = 6, /* the same update for K = 64 / 128 inside the panel recursion (latency-bound kernel) */
-    RFLU_K_COUNT = 7
+    RFLU_K_GEMM_SMALL = 6, /* the same update for K < 256: per-leaf updates and small merges (latency / HBM bound) */
+    RFLU_K_LASWP_WIDE = 7, /* apply_permutation! launches that move >= 32 MiB (trailing-update / finished-columns interchanges:
+                              the bandwidth-bound share; the per-leaf launches stay in RFLU_K_LASWP and are latency-bound) */
+    RFLU_K_COUNT = 8
 };
 
 /* ---- lifetime ---- */

@@ -71,7 +71,7 @@ for _k, _v in _TYPED.items():
         EXPORTS[_k.format(s=_s)] = _v
 
 K_GEMM, K_TRSM, K_LASWP, K_PANEL, K_TRANSPOSE, K_MISC = range(6)
-KCLASS_NAMES = ["gemm", "trsm", "laswp", "panel", "transpose", "misc", "gemm_small"]
+KCLASS_NAMES = ["gemm", "trsm", "laswp", "panel", "transpose", "misc", "gemm_small", "laswp_wide"]
 PATH_NONE, PATH_HIP_RECURSIVE, PATH_HIP_BLOCKED, PATH_HIP_LOOKAHEAD = 0, 1, 2, 3
 
 _lib = None

@@ -823,7 +823,16 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
         // tall block columns (update-bound): factor_lookahead; from the first panel of at most lw_rows rows on: factor_leafwise.
         // RFLU_LEAFWISE=0 keeps the lookahead schedule to the end.
         const char* lw = getenv("RFLU_LEAFWISE");
-        const int leafwise = lw ? atoi(lw) : 1;
+        int leafwise = lw ? atoi(lw) : 1;
+        // rocprofv3 --pmc runs ONE kernel at a time across all queues: a gate kernel waiting for another stream's kernel would
+        // never see it start (the 2 s gate timeout turns that into RFLU_ERR_TIMEOUT).  Counter collection therefore gets the
+        // lookahead schedule, whose cross-stream edges are hipEvents, to the end.
+        if (const char* cc = getenv("ROCPROF_COUNTER_COLLECTION"); cc && atoi(cc) != 0 && !lw) {
+            static bool told = false;
+            if (!told) fprintf(stderr, "[rflu] counter collection serialises kernels: leaf-wise schedule off for this process\n");
+            told = true;
+            leafwise = 0;
+        }
         const int64_t Wb = round_up(blocksize, NB);
         const auto t_enq0 = std::chrono::steady_clock::now();
         const int64_t nblk = (mn + Wb - 1) / Wb;

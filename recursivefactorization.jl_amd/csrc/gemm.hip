@@ -373,7 +373,9 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    ProfScope ps(h, RFLU_K_GEMM, 2.0 * (double)M * (double)N * (double)K,
+    // K < 256: the leaf-wise schedule's per-leaf updates (K = 64) and the recursion's small merges -- HBM/latency-bound launches
+    // that are accounted with the small-K kernel, so that RFLU_K_GEMM is the MFMA-bound bulk update alone
+    ProfScope ps(h, K < 256 ? RFLU_K_GEMM_SMALL : RFLU_K_GEMM, 2.0 * (double)M * (double)N * (double)K,
                  sizeof(T) * ((double)M * K + (double)K * N + 2.0 * (double)M * N));  // A, B once; C in and out
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n;
     if (K < 1024) hipLaunchKernelGGL((gemm_sub_kernel<T, true>), dim3((unsigned)nwg), dim3(256), lds, h->stream, g);

@@ -137,9 +137,9 @@ int launch_laswp3(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64
     int64_t blocks = (ncolsA + LW_COLS - 1) / LW_COLS + (ncolsB + LW_COLS - 1) / LW_COLS +
                      (ncolsC + LW_COLS - 1) / LW_COLS + inv_cnt;
     if (blocks == 0) blocks = 1;   // gates only: one idle workgroup (beyond every range, inv_cnt == 0)
-    ProfScope ps(h, RFLU_K_LASWP, 4.0 * sizeof(T) * (double)NB *
-                                      ((double)(ncolsA + ncolsB) * (double)(chunk1 - chunk0) +
-                                       (double)ncolsC * (double)(chunk1 - chunk0 - 1)));
+    const double moved = 4.0 * sizeof(T) * (double)NB * ((double)(ncolsA + ncolsB) * (double)(chunk1 - chunk0) +
+                                                         (double)ncolsC * (double)(chunk1 - chunk0 - 1));
+    ProfScope ps(h, moved >= 32.0 * 1024 * 1024 ? RFLU_K_LASWP_WIDE : RFLU_K_LASWP, moved);
     hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, h->stream, R, ld, c0, ncolsA, c1, ncolsB, c2,
                        ncolsC, h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk0, (int)chunk1, (int)inv_nb, (int)inv_cnt, inv_L,
                        inv_out, gate);

@@ -12,6 +12,8 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace -- $CMD > $OUT/bench_trace.json 2
 DB=$(find $OUT/trace -name "*.db" | head -1)
 python scripts/rocpd_summary.py $DB > $OUT/kernel_stats.txt
 python scripts/rocpd_queues.py $DB 1 >> $OUT/kernel_stats.txt
+echo "# the profiled single-stream pass (4th factorization of the run): bench.py's roofline.avg_launch_ms is the gemm_sub_kernel average of THIS pass" >> $OUT/kernel_stats.txt
+python scripts/rocpd_queues.py $DB 3 >> $OUT/kernel_stats.txt
 CMD1="python bench.py --size $SIZE --steps 1 --warmup 0 --no-cpu-baseline --no-check --no-extras"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -- $CMD1 > /dev/null 2>$OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -- $CMD1 > /dev/null 2>$OUT/pmc_write.err

@@ -629,6 +629,14 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     auto evUend = [](int64_t b) { return 4 * (size_t)b + 3; };
     // RFLU_CONFINE_ROWS: panels at least this tall run on the stream confined to the reserved CUs (default: never -- the
     // critical path stays on the caller's stream: three active queues in all, see the header comment)
+    // Which of the two masked streams is which.  When the whole matrix is factored leaf-wise (no lookahead part before it) the
+    // SIDE stream gets the 224-CU mask and the update stream the 192-CU one: 32 CUs the bulk GEMM never touches are then always
+    // free for the side stream's per-leaf kernels, and the update has the slack to pay for it (N=4096 12.18 -> 12.03 ms, N=8192
+    // 26.91 -> 26.49).  After a lookahead part the 224-CU stream is still busy with that part's last bulk update when the first
+    // leaf needs the side stream (2.4 ms stall), and moving that update to the 192-CU stream costs what the swap wins (N=16384
+    // 85.1 vs 85.3 ms, N=12288 49.0 vs 48.8): there the update keeps 224 CUs and the side stream takes the 192-CU stream.
+    bool swap_su = b_begin == 0;
+    if (const char* e = getenv("RFLU_SWAP_SU")) swap_su = atoi(e) != 0;
     const bool fold = !(getenv("RFLU_GATE_FOLD") && atoi(getenv("RFLU_GATE_FOLD")) == 0) && !getenv("RFLU_GATE_TRACE");
     int64_t confine_rows = (int64_t)1 << 40;
     if (const char* e = getenv("RFLU_CONFINE_ROWS")) confine_rows = atoll(e);
@@ -692,7 +700,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         // and a taller matrix has already used it for its first block columns -- no fourth queue (see the header comment).
         if (res != 32) { set_error("factor_leafwise: panel of %lld rows needs more than 32 CUs", (long long)(m - j0)); return RFLU_ERR_ARG; }
         hipStream_t S;
-        RFLU_TRY(get_ustream(h, 64, &S));
+        RFLU_TRY(get_ustream(h, swap_su ? 32 : 64, &S));
         {   // the critical path runs on the reserved CUs while the update stream is the bottleneck (see get_pstream)
             hipStream_t to = userS;
             if (m - j0 >= confine_rows && res == 32) RFLU_TRY(get_pstream(h, res, &to));
@@ -754,7 +762,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         Sprev = S;
         // ---- U(b): everything right of block column b+1, and the interchanges nobody needed until now ----
         hipStream_t U;
-        RFLU_TRY(get_ustream(h, reserve_for(m - je), &U));
+        RFLU_TRY(get_ustream(h, swap_su ? 64 : reserve_for(m - je), &U));
         const int64_t glast = g0 + nl - 1;
         {
             h->stream = U;

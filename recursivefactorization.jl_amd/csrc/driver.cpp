@@ -441,20 +441,35 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         return RFLU_OK;
     };
 
-    auto update = [&](hipStream_t st, int64_t j0, int64_t jb, int64_t c0, int64_t c1) -> int {
+    auto update = [&](hipStream_t st, int64_t j0, int64_t jb, int64_t c0, int64_t c1, LaswpGate gate = LaswpGate{},
+                      GemmSignal sig = GemmSignal{}) -> int {
         // apply block column [j0, j0+jb) to columns [c0, c1): interchanges, block-row solve, Schur update
+        // gate: hold the first launch until another stream's counter is reached; sig: publish when the first columns are done
         if (c1 <= c0) return RFLU_OK;
         hipStream_t saved = h->stream;
         h->stream = st;
         int rc = RFLU_OK;
         const int64_t je = j0 + jb;
-        if (f.pivot) rc = launch_laswp<T>(h, R, ld, c0, c1 - c0, j0 / NB, (je + NB - 1) / NB);
+        if (f.pivot) rc = launch_laswp2<T>(h, R, ld, c0, c1 - c0, 0, 0, j0 / NB, (je + NB - 1) / NB, 0, nullptr, nullptr, gate);
+        else if (gate.wait_flag) rc = launch_gate_wait(h, gate.wait_flag, gate.wait_val);
         if (rc == RFLU_OK) rc = trsm_rec<T>(h, jb, c1 - c0, R + j0 * ld + j0, ld, R + j0 * ld + c0, ld, f.linv_at(j0));
         if (rc == RFLU_OK && m > je)
-            rc = launch_gemm<T>(h, m - je, c1 - c0, jb, R + je * ld + j0, ld, R + j0 * ld + c0, ld, R + je * ld + c0, ld);
+            rc = launch_gemm<T>(h, m - je, c1 - c0, jb, R + je * ld + j0, ld, R + j0 * ld + c0, ld, R + je * ld + c0, ld, sig);
         h->stream = saved;
         return rc;
     };
+    // While the update stream is the bottleneck, block column b+2 is not updated by a launch sequence of its own (interchanges,
+    // solves and a 496-tile GEMM that fills 1.1 rounds of the 448 workgroup slots: ~450 us per block column at N=16384) but as the
+    // FIRST tile columns of the one bulk update; the GEMM publishes a gate when those tiles are done and the critical path waits
+    // on that gate instead of an event.
+    int64_t merge_rows = sizeof(T) == 8 ? 8192 : (int64_t)1 << 40;
+    if (const char* e = getenv("RFLU_MERGE_ROWS")) merge_rows = atoll(e);
+    if (const char* cc = getenv("ROCPROF_COUNTER_COLLECTION"); cc && atoi(cc) != 0)
+        merge_rows = (int64_t)1 << 40;   // kernels run one at a time under counter collection: no device-side gates (see getrf_rm)
+    const unsigned long long ubase = h->gate_epoch;
+    h->gate_epoch += (unsigned long long)nblk + 2;
+    auto uval = [&](int64_t b) { return ubase + (unsigned long long)b + 1; };
+    bool prev_merged = false;
 
     // events: 4b+1 = evP[b], 4b+2 = evU1[b], 4b+3 = evUend[b]
     hipStream_t Uprev = nullptr;      // update stream of the previous overlapped block column
@@ -502,6 +517,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
             if (f.pivot && j0 > 0) RFLU_TRY(launch_laswp<T>(h, R, ld, 0, j0, j0 / NB, (je + NB - 1) / NB));
             RFLU_TRY(update(P, j0, jb, je, n));
             prev_overlapped = false;
+            prev_merged = false;
             Uprev = nullptr;
             continue;
         }
@@ -534,15 +550,26 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         // ---- P: next block column (needs rest_{b-1}.part1, which updated exactly these columns).  Handing all but its
         // first leaf to U (and gating P's second leaf on it) was measured slower: U's in-order queue is still busy with
         // rest_{b-1} in the early, update-bound block columns.
+        LaswpGate pgate;
         if (b > 0 && prev_overlapped) {
-            RFLU_TRY(get_event(h, 4 * (b - 1) + 2, &ev));
-            RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
+            if (prev_merged) {
+                pgate.wait_flag = h->gates + 3;
+                pgate.wait_val = uval(b - 1);
+                pgate.info = h->info_dev;
+            } else {
+                RFLU_TRY(get_event(h, 4 * (b - 1) + 2, &ev));
+                RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
+            }
         }
-        RFLU_TRY(update(P, j0, jb, je, n1e));
+        RFLU_TRY(update(P, j0, jb, je, n1e, pgate));
         // ---- U: block column b+2 first (the next `next`), then as much of the rest as fits next to P's work ----
-        RFLU_TRY(update(U, j0, jb, n1e, n2e));
-        RFLU_TRY(get_event(h, 4 * b + 2, &ev));
-        RFLU_HIP(hipEventRecord(ev, U));
+        const bool merged = m - je >= merge_rows && reserve == 32 && jb >= 256 && n2e > n1e && m > je &&
+                            !(b_end < nblk && b == b_end - 1) && b + 1 < nblk;
+        if (!merged) {
+            RFLU_TRY(update(U, j0, jb, n1e, n2e));
+            RFLU_TRY(get_event(h, 4 * b + 2, &ev));
+            RFLU_HIP(hipEventRecord(ev, U));
+        }
         int64_t cA = n;                                                                      // restA = [n2e, cA)
         // With the minimal reservation the masked stream keeps 7/8 of the GPU and a split cannot win more than ~1 %
         // (measured: nothing); it pays for the tall panels, whose reservation takes a quarter to half of the CUs.
@@ -560,7 +587,17 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
             if (left - a >= 512)
                 cA = n1e + a + int64_t(split_share * double(left - a) * double(256 - reserve) / 512.0) / 128 * 128;
         }
-        RFLU_TRY(update(U, j0, jb, n2e, cA));
+        if (merged) {
+            GemmSignal sig;
+            sig.first_cols = n2e - n1e;
+            sig.flag = h->gates + 3;
+            sig.val = uval(b);
+            sig.cnt = reinterpret_cast<unsigned*>(h->gates + 5);
+            RFLU_TRY(update(U, j0, jb, n1e, cA, LaswpGate{}, sig));
+        } else {
+            RFLU_TRY(update(U, j0, jb, n2e, cA));
+        }
+        prev_merged = merged;
         RFLU_TRY(get_event(h, 4 * b + 3, &ev));
         RFLU_HIP(hipEventRecord(ev, U));
         if (cA < n) {

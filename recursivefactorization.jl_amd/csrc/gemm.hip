@@ -73,6 +73,13 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int vec_ok;  // operands 16-byte aligned with even strides: full tiles may use 16-byte loads
     int flags;   // bit0: first operand slab requested BEFORE the C tile; bit1: non-temporal C accesses
+    // "first columns first": the tiles of the first na_tiles_n tile columns take the lowest block indices (they are dispatched,
+    // hence finished, first) and the last of them to finish publishes sig_val in *sig_flag -- the lookahead schedule's
+    // critical path needs only those columns of a bulk update (driver.cpp: factor_lookahead, GemmSignal)
+    int na_tiles_n;
+    unsigned long long* sig_flag;
+    unsigned long long sig_val;
+    unsigned* sig_cnt;
 };
 
 // C_FIRST: the accumulators start as the C tile (its read overlaps with the first operand slabs, the epilogue only
@@ -95,17 +102,22 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
     // ---- workgroup -> tile: bijective XCD-aware remap (block b runs on XCD b % 8; give each XCD a contiguous range
     // of tiles so neighbours share operand panels in that XCD's private L2), then GROUP_M-row grouped ordering.
     int tile_m, tile_n;
+    const int n_first = g.na_tiles_n * g.tiles_m;                 // workgroups of the "first columns" region (0: none)
+    const bool in_first = (int)blockIdx.x < n_first;
     {
-        const int nwg = gridDim.x, bid = blockIdx.x;
+        // two regions, each with the remap of its own: blocks [0, n_first) -> tile columns [0, na), the rest -> [na, tiles_n)
+        const int nwg = in_first ? n_first : (int)gridDim.x - n_first;
+        const int bid = in_first ? (int)blockIdx.x : (int)blockIdx.x - n_first;
+        const int tn = in_first ? g.na_tiles_n : g.tiles_n - g.na_tiles_n;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        const int per_group = G_GROUP_M * g.tiles_n;
+        const int per_group = G_GROUP_M * tn;
         const int group = wg / per_group;
         const int first_m = group * G_GROUP_M;
         const int gsz = min(g.tiles_m - first_m, G_GROUP_M);
         const int in_group = wg - group * per_group;
         tile_m = first_m + in_group % gsz;
-        tile_n = in_group / gsz;
+        tile_n = in_group / gsz + (in_first ? 0 : g.na_tiles_n);
     }
     const int m0 = tile_m * G_BM, n0 = tile_n * G_BN;
 
@@ -229,6 +241,14 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
             }
         }
     }
+    if (in_first && g.sig_flag) {   // workgroup-uniform
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            if (atomicInc(g.sig_cnt, (unsigned)n_first - 1) == (unsigned)n_first - 1)
+                __hip_atomic_store(g.sig_flag, g.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---- latency-bound updates of the panel recursion: K a small multiple of 64, few tiles -------------------------------------
@@ -336,10 +356,11 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs<T> g)
 
 template <typename T>
 int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C,
-                int64_t ldc)
+                int64_t ldc, GemmSignal sig)
 {
     if (M <= 0 || N <= 0 || K <= 0) return RFLU_OK;
     GemmArgs<T> g;
+    g.na_tiles_n = 0; g.sig_flag = nullptr; g.sig_val = 0; g.sig_cnt = nullptr;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.tiles_m = (int)((M + G_BM - 1) / G_BM);
@@ -377,6 +398,10 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
     // that are accounted with the small-K kernel, so that RFLU_K_GEMM is the MFMA-bound bulk update alone
     ProfScope ps(h, K < 256 ? RFLU_K_GEMM_SMALL : RFLU_K_GEMM, 2.0 * (double)M * (double)N * (double)K,
                  sizeof(T) * ((double)M * K + (double)K * N + 2.0 * (double)M * N));  // A, B once; C in and out
+    if (sig.flag && sig.first_cols > 0) {   // only the tiled kernel knows the two-region order (callers use it for K >= 256)
+        g.na_tiles_n = (int)std::min<int64_t>((sig.first_cols + G_BN - 1) / G_BN, g.tiles_n);
+        g.sig_flag = sig.flag; g.sig_val = sig.val; g.sig_cnt = sig.cnt;
+    }
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n;
     if (K < 1024) hipLaunchKernelGGL((gemm_sub_kernel<T, true>), dim3((unsigned)nwg), dim3(256), lds, h->stream, g);
     else          hipLaunchKernelGGL((gemm_sub_kernel<T, false>), dim3((unsigned)nwg), dim3(256), lds, h->stream, g);
@@ -385,9 +410,9 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
 }
 
 template int launch_gemm<double>(Handle*, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t,
-                                 double*, int64_t);
+                                 double*, int64_t, GemmSignal);
 template int launch_gemm<float>(Handle*, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*,
-                                int64_t);
+                                int64_t, GemmSignal);
 
 
 // ---- clock keeper ----------------------------------------------------------------------------------------------------

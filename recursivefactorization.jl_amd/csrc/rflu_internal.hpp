@@ -156,9 +156,17 @@ int ensure_buffer(void** ptr, size_t* cap, size_t need);  // grow-only device bu
 // ---- kernel launchers (each returns an rflu_status); all pointers are device pointers in R layout -----------------------
 int panel_local_rows_per_wg(const Handle* h, int64_t rows);   // panel_local.hip: rows per workgroup of a pivoted leaf
 int launch_heat(Handle* h, int cus, double usec);   // gemm.hip: clock keeper
+// optional early-completion signal of a GEMM launch: the tiles of the first `first_cols` columns of C are computed first and
+// the last of them publishes `val` in *flag (a stream gate, see LaswpGate); cnt: zero-initialised wrapping counter
+struct GemmSignal {
+    int64_t first_cols = 0;
+    unsigned long long* flag = nullptr;
+    unsigned long long val = 0;
+    unsigned* cnt = nullptr;
+};
 template <typename T>
 int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C,
-                int64_t ldc);
+                int64_t ldc, GemmSignal sig = GemmSignal{});
 template <typename T>
 int launch_trsm_base(Handle* h, int64_t nb, int64_t nrhs, const T* L, int64_t ldl, T* B, int64_t ldb);
 // fused strip TRSM (n <= 256) on pre-inverted 64x64 diagonal blocks, and the batched inversion of those blocks

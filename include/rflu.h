@@ -81,12 +81,14 @@ int rflu_debug_gate_stamps(rflu_handle_t handle, long long* out);
 /* ---- the boundary: lu!(A, ipiv, pivot; blocksize) on HOST buffers (caller-owned, column-major) ----
  * Replaces src/lu.jl:114-126 (recursive path + unblocked fallback) for Float64 / Float32.
  * blocksize: < 0 = pure Toledo recursion on the whole matrix, one stream (the reference's structure, src/lu.jl:189-263);
- *            > 0 = width of the outer right-looking block column, each block column factored by the same recursion
- *                  (`blocksize` re-read as the GPU panel width, BASELINE config 3 sweeps
- *                  64/128/256; rounded up to a multiple of 64), with one block column of lookahead: the next block
- *                  column is updated and factored while the rest of the trailing update still runs on a second stream;
+ *            > 0 = width of the outer right-looking block column (`blocksize` re-read as the GPU panel
+ *                  width, BASELINE config 2 sweeps 64/128/256; rounded up to a multiple of 64).  Tall, update-bound block
+ *                  columns: factored by the same recursion with one block column of lookahead (the next block column is
+ *                  updated and factored while the rest of the trailing update still runs on a second stream); from the first
+ *                  panel of at most 8192 rows (Float32: 16384) on, for widths 128..512: leaf by leaf, right-looking, with only
+ *                  the next leaf's 64 columns on the critical path;
  *            = 0 = library default, measured on MI355X: pure recursion below 1024 columns, then block columns of
- *                  128 (<= 8192 columns), 256 (<= 12288), 512 (<= 16384), 1024 (<= 24576), 2048 above. */
+ *                  256 (<= 12288 columns), 512 (<= 16384), 1024 (<= 24576), 2048 above. */
 int rflu_getrf_f64(rflu_handle_t handle, int64_t m, int64_t n, double* A_host, int64_t lda, int64_t* ipiv_host,
                    int pivot, int64_t blocksize, int64_t* info);
 int rflu_getrf_f32(rflu_handle_t handle, int64_t m, int64_t n, float* A_host, int64_t lda, int64_t* ipiv_host,

@@ -17,7 +17,8 @@ Same names, argument meaning and error behaviour; Julia's ``!`` is spelled ``_``
     raise ``TypeError`` (the Julia glue in INTEGRATION.md keeps the reference's own CPU code for those);
   * ``thread`` is accepted and ignored (the GPU path has no thread flag);
   * ``blocksize``: ``None``/0 = library default (pure Toledo recursion below 1024 columns; above, right-looking block
-    columns of 128 ... 2048 by matrix size with one block column of lookahead, see include/rflu.h); negative = pure
+    columns of 256 ... 2048 by matrix size, block-column lookahead for the tall panels and the leaf-wise schedule for
+    panels of at most 8192 rows, see include/rflu.h); negative = pure
     recursion; 64/128/256... = width of the outer right-looking block column.
 
 Inputs: a NumPy array (host; staged through HBM by ``rflu_getrf_*``) or a ``torch`` tensor on the GPU

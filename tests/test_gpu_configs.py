@@ -144,3 +144,37 @@ def test_leafwise_schedule_matches_default(n, bs, monkeypatch):
     scale = float(F.factors.abs().max())
     assert float((F.factors - G.factors).abs().max()) <= 1e-10 * scale
     assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
+
+
+@pytest.mark.parametrize("m,n,bs,dtype,pivot", [
+    (3000, 2048, 128, np.float64, True),     # tall: panels of 3000 .. 952 rows
+    (2048, 3000, 256, np.float64, True),     # fat: the windows of the last block column reach into the tail (src/lu.jl:148-154)
+    (2500, 2500, 192, np.float64, True),     # block width not a power of two, last leaf partial (2500 = 39 * 64 + 4)
+    (3072, 3072, 256, np.float32, True),
+    (2048, 2048, 256, np.float64, False),    # NoPivot: gates as separate one-wave kernels (no interchange launch to ride on)
+])
+def test_leafwise_schedule_rectangular_and_modes(m, n, bs, dtype, pivot, monkeypatch):
+    """Leaf-wise schedule against the CPU oracle on shapes that stress its window arithmetic: pivots bit-exact (Float64),
+    factors within the reference's own bound (test/runtests.jl:19-20)."""
+    from oracle import oracle as O
+    diag = 10.0 if not pivot else 0.0
+    A = O.fill_uniform(m, n, 31 + m + n, dtype)
+    if diag:
+        A[np.arange(min(m, n)), np.arange(min(m, n))] += diag
+    monkeypatch.delenv("RFLU_LEAFWISE", raising=False)
+    W = torch.from_numpy(np.ascontiguousarray(A.T)).to("cuda:0").T      # column-major device view
+    F = rf.lu_(W, None, pivot, check=False, blocksize=bs)
+    assert rf.last_path() == "hip-lookahead" and F.info == 0
+    Fo, ipo, info_o = O.lu(A, pivot=pivot)
+    assert info_o == 0
+    eps = np.finfo(dtype).eps
+    E = 20 * min(m, n) * eps
+    ip = F.ipiv.cpu().numpy() if pivot else np.arange(1, min(m, n) + 1)     # NoPivot with ipiv = None returns NotIPIV
+    if dtype == np.float64 or not pivot:
+        assert np.array_equal(ip, ipo)
+    got = F.factors.cpu().numpy()
+    tol = (10 * np.sqrt(E) if not pivot else 50 * E) * max(1.0, float(np.abs(Fo).max()))
+    if dtype == np.float64 or not pivot:
+        assert float(np.abs(got - Fo).max()) <= tol
+    res, rel = O.residual(A, got, ip)
+    assert res <= (E if pivot else 10 * np.sqrt(E)) * max(1.0, float(np.abs(A).max())) * 4

@@ -256,7 +256,7 @@ struct Fact {
         // one launch: the leaf's interchanges on the other columns + the inverse of its diagonal block (fused TRSMs)
         if (pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, sw_lo, c0 - sw_lo, c0 + w, hi - (c0 + w), r0 / NB, r0 / NB + 1, w,
                                              R + r0 * ld + c0, linv_at(r0)));
-        else RFLU_TRY(launch_diag_inv<T>(h, w, R + r0 * ld + c0, ld, linv_at(r0)));
+        // (NoPivot: launch_panel has already inverted the diagonal block into linv_at(r0), next to inv(U11) for its own rows)
         return RFLU_OK;
     }
 
@@ -767,7 +767,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             } else {
                 if (wflag) RFLU_TRY(launch_gate_wait(h, wflag, val(g - 1)));
                 if (f.pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0)));
-                else RFLU_TRY(launch_diag_inv<T>(h, w, R + c0 * ld + c0, ld, f.linv_at(c0)));
+
                 RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g), stamp(0, g)));
             }
             RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));

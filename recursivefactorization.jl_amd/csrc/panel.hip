@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "panel_common.hpp"
+#include "trsm_row.hpp"
 
 namespace rflu {
 
@@ -787,10 +788,12 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_pair_kernel(PanelAr
 //   kernel 1 (one workgroup): unpivoted LU of the w x w top block, in place.
 //   kernel 2 (G workgroups) : every row below solves  l_i * U11 = a_i  against the factored top block held in LDS.
 // =====================================================================================================================
+constexpr int NPT_THREADS = 256;   // 64 rows x 4 column phases: every thread has work, half the waves at the two barriers per column
 template <typename T>
-__global__ void __launch_bounds__(PANEL_THREADS) panel_nopivot_top_kernel(PanelArgs<T> p)
+__global__ void __launch_bounds__(NPT_THREADS) panel_nopivot_top_kernel(PanelArgs<T> p)
 {
     __shared__ T s_U[NB * TILE_LD];
+    constexpr int PANEL_WAVES = NPT_THREADS / 64;   // (shadows the 8 waves of the cooperative leaves)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w = p.w;
     for (int rr = wave; rr < NB; rr += PANEL_WAVES) {
@@ -852,6 +855,7 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_nopivot_rows_kernel(Panel
     __shared__ T s_U[NB * TILE_LD];  // factored top block L11\U11 (only U11 is used)
     __shared__ int s_spos[64];
 
+    if (p.info[0] == 0) return;   // regular case: panel_nopivot_rows_mfma_kernel has done these rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x;
     const int w = p.w;
@@ -872,6 +876,70 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_nopivot_rows_kernel(Panel
     load_rows<T, RT>(p.R, p.ld, row_base, p.m, p.c0, w, a, s_tile, wave, lane);  // contains __syncthreads
     NoPivotSteps<T, RT, 0, NB>::run(w, s_U, a);
     store_rows<T, RT>(p.R, p.ld, p.c0, w, a, pos, s_tile, s_spos, wave, lane);
+}
+
+// NoPivot leaf, round 2: the rows below are  L21 = A21 * inv(U11)  as an MFMA product instead of a 64-step substitution per
+// row (59 -> ~10 us at 16384 rows).  After the top block's LU one launch of two workgroups inverts L11 (for the TRSMs that
+// follow, as the pivoted path does in its interchange launch) and U11; the product kernel needs no LDS.  A zero pivot
+// (info != 0) makes inv(U11) meaningless: then -- and only then -- the substitution kernel does the rows, with the
+// reference's zero-pivot-continue semantics (src/lu.jl:316-330); both kernels are launched and one of them returns at once.
+template <typename T>
+__global__ void __launch_bounds__(256) panel_nopivot_inv_kernel(PanelArgs<T> p, T* __restrict__ linv, T* __restrict__ uinv)
+{
+    __shared__ T sL[NB * NB];
+    __shared__ T sX[NB * NB];
+    const T* blk = p.R + (int64_t)p.r0 * p.ld + p.c0;
+    if (blockIdx.x == 0) diag_inv_block4<T, false>(p.w, blk, p.ld, linv, sL, sX, threadIdx.x);
+    else if (p.info[0] == 0) diag_inv_block4<T, true>(p.w, blk, p.ld, uinv, sL, sX, threadIdx.x);
+}
+
+template <typename T>
+struct NpMfma;
+template <>
+struct NpMfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct NpMfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+// one workgroup = 64 rows below the top block, wave = 16 of them: X = A21 * inv(U11), in place
+template <typename T>
+__global__ void __launch_bounds__(256) panel_nopivot_rows_mfma_kernel(PanelArgs<T> p, const T* __restrict__ uinv)
+{
+    if (p.info[0] != 0) return;   // a zero pivot somewhere: the substitution kernel takes over (uniform for the whole grid)
+    typedef typename NpMfma<T>::acc_t acc_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fk = lane >> 4;
+    const int w = p.w;
+    const int64_t row0 = (int64_t)p.r0 + w + (int64_t)blockIdx.x * 64 + wave * 16;
+    T a[16];
+    {
+        const bool rok = row0 + fi < p.m;
+        const T* Ap = p.R + (row0 + fi) * p.ld + p.c0 + fk;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) a[kk] = (rok && kk * 4 + fk < w) ? Ap[kk * 4] : T(0);
+    }
+    acc_t x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = NpMfma<T>::run(a[kk], uinv[(kk * 4 + fk) * NB + t * 16 + fi], x[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + NpMfma<T>::crow(lane, r);
+            const int col = t * 16 + fi;
+            if (row < p.m && col < w) p.R[row * p.ld + p.c0 + col] = x[t][r];
+        }
 }
 
 template <typename T>
@@ -926,9 +994,14 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
             else hipLaunchKernelGGL((panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
         }
     } else {
-        hipLaunchKernelGGL((panel_nopivot_top_kernel<T>), dim3(1), dim3(PANEL_THREADS), 0, h->stream, p);
+        hipLaunchKernelGGL((panel_nopivot_top_kernel<T>), dim3(1), dim3(NPT_THREADS), 0, h->stream, p);
+        // inverses: L11 -> this leaf's slot of h->linv (what launch_diag_inv would compute), U11 -> the spare last slot
+        T* linv = static_cast<T*>(h->linv) + (r0 / NB) * NB * NB;
+        T* uinv = static_cast<T*>(h->linv) + (h->pm_chunks - 1) * NB * NB;
+        hipLaunchKernelGGL((panel_nopivot_inv_kernel<T>), dim3(2), dim3(256), 0, h->stream, p, linv, uinv);
         const int64_t below = rows - w;
         if (below > 0) {
+            hipLaunchKernelGGL((panel_nopivot_rows_mfma_kernel<T>), dim3((unsigned)((below + 63) / 64)), dim3(256), 0, h->stream, p, uinv);
             const int gb = (int)((below + (int64_t)PANEL_THREADS * rt - 1) / ((int64_t)PANEL_THREADS * rt));
             hipLaunchKernelGGL((panel_nopivot_rows_kernel<T, 1>), dim3(gb), dim3(PANEL_THREADS), 0, h->stream, p);
         }

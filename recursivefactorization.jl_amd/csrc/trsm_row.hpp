@@ -49,7 +49,9 @@ struct TrsmRowG {
 };
 
 // sL, sX: NB*NB elements of LDS each.  All 256 threads of the workgroup must call this.
-template <typename T>
+// UPPER: the block is the NON-unit UPPER triangle U of the same storage and the result is inv(U): U' = L'*D with the unit lower
+// L'[i][j] = U[j][i] / U[j][j], so inv(U)[i][j] = inv(L')[j][i] / U[j][j] -- the same machinery on the scaled transpose.
+template <typename T, bool UPPER = false>
 __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lblk, int64_t ldl, T* __restrict__ Linv,
                                                 T* sL, T* sX, int tid)
 {
@@ -60,7 +62,9 @@ __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lb
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int j = c0 + e;
-            sL[i * NB + j] = (i < nb && j < i) ? Lblk[(int64_t)i * ldl + j] : T(0);
+            T v = T(0);
+            if (i < nb && j < i) v = UPPER ? Lblk[(int64_t)j * ldl + i] / Lblk[(int64_t)j * ldl + j] : Lblk[(int64_t)i * ldl + j];
+            sL[i * NB + j] = v;
             sX[i * NB + j] = T(0);
         }
     }
@@ -111,7 +115,11 @@ __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lb
     {
         const int i = tid >> 2, c0 = (tid & 3) * 16;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Linv[i * NB + c0 + e] = sX[i * NB + c0 + e];
+        for (int e = 0; e < 16; ++e) {
+            const int j = c0 + e;
+            if (UPPER) Linv[i * NB + j] = sX[j * NB + i] / (j < nb ? Lblk[(int64_t)j * ldl + j] : T(1));
+            else Linv[i * NB + j] = sX[i * NB + j];
+        }
     }
 }
 

@@ -672,7 +672,8 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     // 26.91 -> 26.49).  After a lookahead part the 224-CU stream is still busy with that part's last bulk update when the first
     // leaf needs the side stream (2.4 ms stall), and moving that update to the 192-CU stream costs what the swap wins (N=16384
     // 85.1 vs 85.3 ms, N=12288 49.0 vs 48.8): there the update keeps 224 CUs and the side stream takes the 192-CU stream.
-    bool swap_su = b_begin == 0;
+    // (Float32 at N=16384 is leaf-wise from block column 0 as well, but there the update still needs its 224 CUs: 63.9 vs 62.1 ms.)
+    bool swap_su = b_begin == 0 && m <= 8192;
     if (const char* e = getenv("RFLU_SWAP_SU")) swap_su = atoi(e) != 0;
     const bool fold = !(getenv("RFLU_GATE_FOLD") && atoi(getenv("RFLU_GATE_FOLD")) == 0) && !getenv("RFLU_GATE_TRACE");
     int64_t confine_rows = (int64_t)1 << 40;

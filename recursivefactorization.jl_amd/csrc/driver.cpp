@@ -243,7 +243,6 @@ struct Fact {
     int pivot;
     int64_t sw_lo = 0, sw_hi = -1;  // column range that receives a leaf's interchanges right away ([0, n) by default)
     int64_t roff = 0;               // row of the diagonal minus its column (non-zero for a block column of a slab)
-    hipEvent_t gate = nullptr;      // if set: wait for it after the next leaf's panel kernel, before its interchanges
 
     T* linv_at(int64_t row) const { return static_cast<T*>(h->linv) + (row / NB) * NB * NB; }
 
@@ -615,7 +614,6 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     RFLU_TRY(move_P(userS, nblk));
     f.sw_lo = 0;
     f.sw_hi = -1;
-    f.gate = nullptr;
     if (U_last) *U_last = Uprev;
     if (b_end < nblk) return RFLU_OK;   // factor_leafwise goes on from here and joins at its end
     // join: P continues only after U has drained

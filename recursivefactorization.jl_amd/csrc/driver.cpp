@@ -234,6 +234,12 @@ static int gemm_public(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, i
     return RFLU_OK;
 }
 
+// measured on MI355X (bench.py --blocksize sweep): the knee moves right with the matrix size
+static int64_t default_blocksize(int64_t mn)
+{
+    return mn < 1024 ? -1 : (mn <= 12288 ? 256 : (mn <= 16384 ? 512 : (mn <= 24576 ? 1024 : 2048)));
+}
+
 template <typename T>
 struct Fact {
     Handle* h;
@@ -243,6 +249,7 @@ struct Fact {
     int pivot;
     int64_t sw_lo = 0, sw_hi = -1;  // column range that receives a leaf's interchanges right away ([0, n) by default)
     int64_t roff = 0;               // row of the diagonal minus its column (non-zero for a block column of a slab)
+    hipEvent_t tail = nullptr;      // columns right of the first block column become valid with this event (getrf_cm_dev)
 
     T* linv_at(int64_t row) const { return static_cast<T*>(h->linv) + (row / NB) * NB * NB; }
 
@@ -501,6 +508,10 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         f.sw_lo = j0;
         f.sw_hi = je;
         RFLU_TRY(f.rec(j0, je));
+        if (b == 0 && f.tail) {   // everything after the first panel may touch the columns whose layout change ran next to it
+            RFLU_HIP(hipStreamWaitEvent(P, f.tail, 0));
+            f.tail = nullptr;
+        }
         RFLU_TRY(flush_pending());                                   // restB_{b-1}: whole GPU, after the panel
         // the panel that will run next to this block column's update is panel b+1
         const int64_t rows_next = m - je;
@@ -857,8 +868,16 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
 
     Fact<T> f{h, R, ld, m, n, ipiv, pivot};
     bool fat_tail_done = false;
-    if (blocksize == 0)  // measured on MI355X (bench.py --blocksize sweep): the knee moves right with the matrix size
-        blocksize = mn < 1024 ? -1 : (mn <= 12288 ? 256 : (mn <= 16384 ? 512 : (mn <= 24576 ? 1024 : 2048)));
+    if (blocksize == 0) blocksize = default_blocksize(mn);
+    // column-major entry with the tail of the layout change still in flight (getrf_cm_dev): only factor_lookahead knows where the
+    // first access to those columns is; every other path waits for it here
+    hipEvent_t tail = h->tail_event;
+    h->tail_event = nullptr;
+    const bool two_stream = !(blocksize < 0 || blocksize >= mn) && !h->prof && h->num_cus == 256;
+    if (tail && !two_stream) {
+        RFLU_HIP(hipStreamWaitEvent(h->stream, tail, 0));
+        tail = nullptr;
+    }
     if (blocksize < 0 || blocksize >= mn) {
         h->last_path = RFLU_PATH_HIP_RECURSIVE;
         RFLU_TRY(f.rec(0, mn));
@@ -892,6 +911,11 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             b_switch = m <= lw_rows ? 0 : std::min(nblk, (m - lw_rows + Wb - 1) / Wb);
         }
         hipStream_t U_last = nullptr;
+        if (tail && b_switch == 0) {
+            RFLU_HIP(hipStreamWaitEvent(h->stream, tail, 0));
+            tail = nullptr;
+        }
+        f.tail = tail;
         if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last));
         if (b_switch < nblk) RFLU_TRY(factor_leafwise<T>(f, Wb, b_switch, U_last));
         if (getenv("RFLU_TIME_ENQUEUE"))
@@ -936,8 +960,34 @@ static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int6
     const int64_t ldr = round_up(n, 16);
     RFLU_TRY(ensure_buffer(&h->work, &h->work_bytes, (size_t)m * (size_t)ldr * sizeof(T)));
     T* R = static_cast<T*>(h->work);
-    RFLU_TRY(launch_transpose<T>(h, m, n, A, lda, R, ldr));
-    RFLU_TRY(getrf_rm<T>(h, m, n, R, ldr, ipiv, pivot, blocksize, info));
+    // Layout change in two pieces: the first block column on the caller's stream, the rest on the CU-masked update stream while
+    // the first panel (2.3 ms on 32 CUs at N=16384, nothing else to do) already runs.
+    const int64_t mn = std::min(m, n);
+    int64_t W0 = blocksize == 0 ? default_blocksize(mn) : blocksize;
+    W0 = W0 > 0 ? round_up(W0, NB) : 0;
+    static const bool tail_overlap = [] { const char* e = getenv("RFLU_TAIL_OVERLAP"); return e == nullptr || atoi(e) != 0; }();
+    if (tail_overlap && !h->prof && h->num_cus == 256 && mn >= 12288 && W0 > 0 && W0 < mn && n - W0 >= 4096) {
+        if (!h->tail_event_obj) {
+            RFLU_HIP(hipEventCreateWithFlags(&h->tail_event_obj, hipEventDisableTiming));
+            RFLU_HIP(hipEventCreateWithFlags(&h->tail_fork_obj, hipEventDisableTiming));
+        }
+        hipStream_t U0, user = h->stream;
+        RFLU_TRY(get_ustream(h, 32, &U0));
+        RFLU_HIP(hipEventRecord(h->tail_fork_obj, user));            // whatever produced A on the caller's stream
+        RFLU_HIP(hipStreamWaitEvent(U0, h->tail_fork_obj, 0));
+        RFLU_TRY(launch_transpose<T>(h, m, W0, A, lda, R, ldr));
+        h->stream = U0;
+        const int rc = launch_transpose<T>(h, m, n - W0, A + W0 * lda, lda, R + W0, ldr);
+        h->stream = user;
+        RFLU_TRY(rc);
+        RFLU_HIP(hipEventRecord(h->tail_event_obj, U0));
+        h->tail_event = h->tail_event_obj;
+    } else {
+        RFLU_TRY(launch_transpose<T>(h, m, n, A, lda, R, ldr));
+    }
+    const int rc_f = getrf_rm<T>(h, m, n, R, ldr, ipiv, pivot, blocksize, info);
+    h->tail_event = nullptr;
+    RFLU_TRY(rc_f);
     RFLU_TRY(launch_transpose<T>(h, n, m, R, ldr, A, lda));
     RFLU_HIP(hipStreamSynchronize(h->stream));
     return RFLU_OK;
@@ -1093,6 +1143,8 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->pscratch) (void)hipFree(h->pscratch);
     if (h->info_dev) (void)hipFree(h->info_dev);
     if (h->gates) (void)hipFree(h->gates);
+    if (h->tail_event_obj) (void)hipEventDestroy(h->tail_event_obj);
+    if (h->tail_fork_obj) (void)hipEventDestroy(h->tail_fork_obj);
     if (h->gate_stamps) (void)hipFree(h->gate_stamps);
     if (h->info_pinned) (void)hipHostFree(h->info_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -53,6 +53,9 @@ struct Handle {
     hipStream_t ustreams[8] = {};     // ustreams[r]: CU mask leaving 32*r CUs to the critical path (r = 1..7)
     hipStream_t pstreams[8] = {};     // pstreams[r]: the complement -- exactly those 32*r CUs (critical path of the update-bound phase)
     bool panel_attr_set[2][2] = {};        // [Float64|Float32][64|128 rows]: dynamic-LDS attribute of the small-workgroup leaves
+    hipEvent_t tail_event = nullptr;       // column-major entry: the columns right of the first block column are still being
+                                           // transposed on the update stream; set = pending, consumed by getrf_rm
+    hipEvent_t tail_event_obj = nullptr, tail_fork_obj = nullptr;
     unsigned long long* gates = nullptr;   // device: [0] critical path, [1] side stream 1, [2] side stream 2 (leaf counters)
     unsigned long long* gate_ptr[3] = {};  // the three counters
     unsigned long long gate_epoch = 0;     // counters only grow: leaf g of a factorization is gate_epoch + g + 1

@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(256) transpose_kernel(int64_t rows_out, int64_
 {
     __shared__ T tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    // diagonal block order: with a power-of-two leading dimension the tiles of one block row start 2^k bytes apart and camp on
+    // the same HBM channels; shifting the tile row by the tile column spreads the workgroups in flight over all of them
+    const int64_t r0 = (int64_t)((blockIdx.y + blockIdx.x) % gridDim.y) * 64, c0 = (int64_t)blockIdx.x * 64;
     // read in[c0 + i][r0 + tx] (coalesced along in's rows)
     for (int i = ty; i < 64; i += 4) {
         const int64_t ir = c0 + i, ic = r0 + tx;

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librflu.so")
+LIB_PATH = os.environ.get("RFLU_LIB") or os.path.join(HERE, "librflu.so")   # RFLU_LIB: experiment builds (scripts/)
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int

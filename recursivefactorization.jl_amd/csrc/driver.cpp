@@ -351,6 +351,7 @@ static int get_masked_stream(Handle* h, hipStream_t* slot, int r)
         for (int i = 0; i < 8; ++i) mask[i] = (i < r || i >= words) ? 0u : 0xffffffffu;
         if (words <= r || hipExtStreamCreateWithCUMask(slot, (uint32_t)words, mask) != hipSuccess) {
             (void)hipGetLastError();
+            h->mask_failed = true;
             RFLU_HIP(hipStreamCreateWithFlags(slot, hipStreamNonBlocking));
         }
     }
@@ -472,6 +473,11 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     if (const char* e = getenv("RFLU_MERGE_ROWS")) merge_rows = atoll(e);
     if (const char* cc = getenv("ROCPROF_COUNTER_COLLECTION"); cc && atoi(cc) != 0)
         merge_rows = (int64_t)1 << 40;   // kernels run one at a time under counter collection: no device-side gates (see getrf_rm)
+    {   // the gate needs P and U to run concurrently: only with a real CU-masked update stream (create it now to find out)
+        hipStream_t probe;
+        RFLU_TRY(get_ustream(h, 32, &probe));
+        if (h->mask_failed) merge_rows = (int64_t)1 << 40;
+    }
     const unsigned long long ubase = h->gate_epoch;
     h->gate_epoch += (unsigned long long)nblk + 2;
     auto uval = [&](int64_t b) { return ubase + (unsigned long long)b + 1; };
@@ -845,6 +851,341 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     return RFLU_OK;
 }
 
+// Deep-lookahead schedule (round 3): the pivot chain and the bulk update overlap from the first block column to the last.
+//
+// factor_lookahead / factor_leafwise keep the update stream right-looking and in order: block column b+1 becomes current only
+// when U has applied block column b to EVERYTHING, so a factorization runs as an update-bound half (the chain waits) followed
+// by a chain-bound half (the update stream idles); floor ~72 ms at N=16384 with both resources at ~52-55 ms.  Here U keeps,
+// per column block c, a[c] = "block columns [0, a[c]) have been applied" and s[c] = "the interchanges of block columns
+// [0, s[c]) have been applied" (s >= a), and works in SWEEPS: after block column b is factored it brings the columns right of
+// the window up to date left to right -- nearest (= needed soonest) first -- and stops where a cost model says the next block
+// column will be finished; what it did not reach stays behind and is picked up by later sweeps, several block columns at a
+// time as ONE update with K = (number of pending block columns) * W (fewer passes over C, better MFMA rate).
+// Interchanges: at the start of sweep(b) every finished L column takes block column b's interchanges (as in the round-2
+// schedules), so all of L is always in the CURRENT row order; a lagging column group first receives the interchanges it has
+// missed and is then updated against L in that same row order.  P (A - L U) = P A - (P L) U: permuting the rows below a block row
+// consistently on both sides commutes with that block row's elimination, so every entry still receives the eliminations of
+// src/lu.jl:229-246 in the same order -- only WHEN a far column receives them changes, and how many share one K loop.
+//   P (caller's stream)  : the chain.  Tall panels (> lw_rows rows): Toledo recursion on the block column, then the update of
+//                          block column b+1.  Short panels: leaf by leaf as in factor_leafwise.
+//   S (side stream)      : tall panels: block column b applied to the WINDOW [b+2, b+1+dwin] right after it is factored (the
+//                          window is what lets U be late without the chain noticing: only the column block that ENTERS the window
+//                          comes from U, and it is the last thing S touches); short panels: the per-leaf updates of
+//                          factor_leafwise (rest of the block column, next block column).
+//   U (update stream)    : the sweeps and the interchanges on finished L columns.
+// Three queues in all (DESIGN.md "queues").  Cross-stream edges once per block column: hipEvents, and one device-side gate where
+// the waiter is the chain itself.
+template <typename T>
+static int factor_deep(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U_before, int64_t lw_rows)
+{
+    Handle* h = f.h;
+    const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
+    T* R = f.R;
+    const hipStream_t userS = h->stream;
+    struct Restore { Handle* h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, userS};
+    const hipStream_t P = userS;
+    const int64_t nblk = (mn + W - 1) / W, nleaf = (mn + NB - 1) / NB, ncb = (n + W - 1) / W;
+    auto evS = [](int64_t b) { return 4 * (size_t)b + 0; };
+    auto evP = [](int64_t b) { return 4 * (size_t)b + 1; };
+    auto evU1 = [](int64_t b) { return 4 * (size_t)b + 2; };
+    auto evUend = [](int64_t b) { return 4 * (size_t)b + 3; };
+    bool swap_su = b_begin == 0 && m <= 8192;   // see factor_leafwise
+    if (const char* e = getenv("RFLU_SWAP_SU")) swap_su = atoi(e) != 0;
+    const bool fold = !(getenv("RFLU_GATE_FOLD") && atoi(getenv("RFLU_GATE_FOLD")) == 0) && !getenv("RFLU_GATE_TRACE");
+    int64_t dwin = 3;
+    if (const char* e = getenv("RFLU_DEEP_WIN")) dwin = std::max<int64_t>(1, atoll(e));
+    double scale_rec = 1.3, scale_leaf = 1.3;    // share of a block column's time a sweep may fill: the side stream's updates share
+                                                 // the CUs, and in the leaf-wise part nothing absorbs a sweep that runs long
+    if (const char* e = getenv("RFLU_DEEP_SCALE")) scale_rec = atof(e);
+    if (const char* e = getenv("RFLU_DEEP_SCALE_LEAF")) scale_leaf = atof(e);
+    int64_t kmax = 1;            // at most this many pending block columns share one update (K = kmax * W)
+    if (const char* e = getenv("RFLU_DEEP_KMAX")) kmax = std::max<int64_t>(1, atoll(e));
+    int64_t Q = 8;               // a sweep cuts a column group only at multiples of Q column blocks (no slivers)
+    if (const char* e = getenv("RFLU_DEEP_Q")) Q = std::max<int64_t>(1, atoll(e));
+    const bool trace = getenv("RFLU_DEEP_TRACE") != nullptr;
+    auto wait_on = [&](hipStream_t st, size_t idx) -> int {
+        hipEvent_t e;
+        RFLU_TRY(get_event(h, idx, &e));
+        RFLU_HIP(hipStreamWaitEvent(st, e, 0));
+        return RFLU_OK;
+    };
+    auto record_on = [&](hipStream_t st, size_t idx) -> int {
+        hipEvent_t e;
+        RFLU_TRY(get_event(h, idx, &e));
+        RFLU_HIP(hipEventRecord(e, st));
+        return RFLU_OK;
+    };
+    hipStream_t S, U;
+    RFLU_TRY(get_ustream(h, swap_su ? 32 : 64, &S));
+    RFLU_TRY(get_ustream(h, swap_su ? 64 : 32, &U));
+    if (b_begin > 0) {   // everything right of block column b_begin was last written by factor_lookahead's update stream
+        if (U_before && U_before != U) RFLU_TRY(wait_on(U, evUend(b_begin - 1)));
+        if (U_before && U_before != S) RFLU_TRY(wait_on(S, evUend(b_begin - 1)));
+    }
+    if (f.tail) {   // column-major entry: the layout change of the columns right of the first block column is still in flight
+        RFLU_HIP(hipStreamWaitEvent(S, f.tail, 0));
+        RFLU_HIP(hipStreamWaitEvent(U, f.tail, 0));
+    }
+    auto chunk_of = [&](int64_t blk) { return (std::min(blk * W, mn) + NB - 1) / NB; };   // first pivot chunk of block column blk
+    // leaf (columns c0..c0+w) applied to columns [a, b): interchanges (optional), block-row solve, Schur update (K = w)
+    auto apply_leaf = [&](hipStream_t st, int64_t c0, int64_t w, int64_t a, int64_t b, bool swaps) -> int {
+        if (b <= a) return RFLU_OK;
+        hipStream_t saved = h->stream;
+        h->stream = st;
+        int rc = RFLU_OK;
+        if (swaps && f.pivot) rc = launch_laswp<T>(h, R, ld, a, b - a, c0 / NB, c0 / NB + 1);
+        if (rc == RFLU_OK) rc = launch_trsm_inv64<T>(h, w, b - a, f.linv_at(c0), R + c0 * ld + a, ld);
+        if (rc == RFLU_OK && m > c0 + w)
+            rc = launch_gemm<T>(h, m - c0 - w, b - a, w, R + (c0 + w) * ld + c0, ld, R + c0 * ld + a, ld, R + (c0 + w) * ld + a, ld);
+        h->stream = saved;
+        return rc;
+    };
+    // columns [c0, c1): the interchanges of block columns [s0, s1), then block columns [ja, jz) as ONE update:
+    // block-row solve against the (jz - ja) W triangle, Schur update with K = (jz - ja) W
+    auto advance = [&](hipStream_t st, int64_t s0, int64_t s1, int64_t ja, int64_t jz, int64_t c0, int64_t c1,
+                       LaswpGate gate = LaswpGate{}) -> int {
+        if (c1 <= c0) return RFLU_OK;
+        const int64_t r0 = ja * W, r1 = std::min(jz * W, mn), k = r1 - r0;
+        hipStream_t saved = h->stream;
+        h->stream = st;
+        int rc = RFLU_OK;
+        if (f.pivot && s1 > s0) rc = launch_laswp2<T>(h, R, ld, c0, c1 - c0, 0, 0, chunk_of(s0), chunk_of(s1), 0, nullptr, nullptr, gate);
+        else if (gate.wait_flag) rc = launch_gate_wait(h, gate.wait_flag, gate.wait_val);
+        if (rc == RFLU_OK && k > 0) rc = trsm_rec<T>(h, k, c1 - c0, R + r0 * ld + r0, ld, R + r0 * ld + c0, ld, f.linv_at(r0));
+        if (rc == RFLU_OK && k > 0 && m > r1)
+            rc = launch_gemm<T>(h, m - r1, c1 - c0, k, R + r1 * ld + r0, ld, R + r0 * ld + c0, ld, R + r1 * ld + c0, ld);
+        h->stream = saved;
+        return rc;
+    };
+    // ---- cost model (microseconds): what the chain needs for a block column, what an update costs on the masked stream ----
+    auto is_leaf_mode = [&](int64_t b) { return m - b * W <= lw_rows; };
+    auto chain_us = [&](int64_t b) -> double {   // from "block column b-1 factored" to "block column b factored"
+        if (b >= nblk) return 0.0;
+        const int64_t j0 = b * W, jb = std::min(W, mn - j0), rows = m - j0;
+        const double G = double((rows + PANEL_THREADS - 1) / PANEL_THREADS);
+        if (is_leaf_mode(b)) return double((jb + NB - 1) / NB) * (NB * (2.6 + 0.025 * G) + 45.0);
+        return model_panel_us(rows, jb) + 120.0 + 2.0 * double(rows) * double(jb) * double(W) / model_gemm_flops_per_us(W, 256, sizeof(T));
+    };
+    auto task_us = [&](int64_t ja, int64_t jz, int64_t ncols) -> double {
+        const int64_t r0 = ja * W, r1 = std::min(jz * W, mn), k = r1 - r0;
+        double t = 40.0 + 15.0 * double(k) / 128.0                          // launches: interchanges, solve strips / merges, update
+                   + double(k) * double(k) * double(ncols) / 25e6;            // the triangle's own flops (small-K GEMMs + strips)
+        if (m > r1) t += 2.0 * double(m - r1) * double(ncols) * double(k) / model_gemm_flops_per_us(k, 224, sizeof(T));
+        return t;
+    };
+    auto swap_us = [&](int64_t s0, int64_t s1, int64_t ncols) -> double {
+        return s1 > s0 && f.pivot ? 10.0 + 4.0 * sizeof(T) * double(ncols) * double((s1 - s0) * W) / 2.4e6 : 0.0;
+    };
+    std::vector<int64_t> a((size_t)ncb + 1, b_begin);    // a[c]: block columns [0, a[c]) have been applied to column block c
+    std::vector<int64_t> sw((size_t)ncb + 1, b_begin);   // sw[c]: ... and the interchanges of block columns [0, sw[c])
+    double tU = 0.0, tE = 0.0;   // model clocks: the update stream; the chain at "block column b factored"
+    // Sweep after block column b: columns [rs, ncb) towards a = b + 1, nearest first.  Column block rs is REQUIRED (the window /
+    // the next block column takes it over next).  Beyond it: run by run (equally old neighbours); a run that is one block column
+    // behind is cut by columns when the budget ends (at a multiple of Q column blocks), an older run is advanced over its whole
+    // width by as many block columns as fit (<= kmax per update).  all = no budget: bring everything up to date.
+    auto sweep = [&](int64_t b, int64_t rs, double budget, bool all) -> int {
+        const int64_t target = b + 1;
+        double used = 0.0;
+        auto run = [&](int64_t jz, int64_t c, int64_t c2) -> int {   // column blocks [c, c2): interchanges up to date, a -> jz
+            const int64_t x0 = c * W, x1 = std::min(c2 * W, n);
+            const int64_t ja = a[c], s0 = sw[c];
+            RFLU_TRY(advance(U, s0, target, ja, jz, x0, x1));
+            const double t = task_us(ja, jz, x1 - x0) + swap_us(s0, target, x1 - x0);
+            used += t;
+            if (trace) fprintf(stderr, "[deep] sweep %lld: block columns %lld..%lld -> column blocks %lld..%lld (%.0f us; used %.0f of %.0f)\n",
+                               (long long)b, (long long)ja, (long long)jz - 1, (long long)c, (long long)c2 - 1, t, used, budget);
+            for (int64_t cc = c; cc < c2; ++cc) { a[cc] = jz; sw[cc] = target; }
+            return RFLU_OK;
+        };
+        auto run_end = [&](int64_t c) { int64_t c2 = c + 1; while (c2 < ncb && a[c2] == a[c] && sw[c2] == sw[c]) ++c2; return c2; };
+        if (rs < ncb && a[rs] < target) {   // the required column block: with its whole run if that fits, alone otherwise
+            int64_t c2 = run_end(rs);
+            double full = 0.0;
+            for (int64_t j = a[rs]; j < target; j += kmax) full += task_us(j, std::min(j + kmax, target), std::min(c2 * W, n) - rs * W);
+            if (!all && full > budget * 1.15) {
+                const int64_t fit = (int64_t)(double(c2 - rs) * budget / full / double(Q) + 0.5) * Q;
+                c2 = rs + std::max<int64_t>(1, std::min(fit, c2 - rs));
+            }
+            while (a[rs] < target) RFLU_TRY(run(std::min(a[rs] + kmax, target), rs, c2));
+        }
+        RFLU_TRY(record_on(U, evU1(b)));
+        for (int64_t c = rs; c < ncb;) {
+            if (a[c] >= target) { ++c; continue; }
+            const int64_t c2 = run_end(c);
+            const int64_t ncols = std::min(c2 * W, n) - c * W;
+            bool stop = false;
+            while (a[c] < target && !stop) {
+                int64_t kk = std::min(kmax, target - a[c]);
+                const double sus = swap_us(sw[c], target, ncols);
+                while (!all && kk >= 1 && used + sus + task_us(a[c], a[c] + kk, ncols) > budget * 1.1) --kk;
+                if (kk >= 1) {
+                    RFLU_TRY(run(a[c] + kk, c, c2));
+                    continue;
+                }
+                // not even one block column over the whole run: what fits of it, by columns (whole multiples of Q column blocks)
+                const double t1 = task_us(a[c], a[c] + 1, ncols) + sus;
+                const int64_t fit = (int64_t)(double(c2 - c) * (budget - used) / t1 / double(Q) + 0.5) * Q;
+                if (fit >= Q && fit < c2 - c) RFLU_TRY(run(a[c] + 1, c, c + fit));
+                else if (fit >= c2 - c) RFLU_TRY(run(a[c] + 1, c, c2));
+                stop = true;
+            }
+            if (stop) break;
+            c = c2;
+        }
+        tU += used;
+        return RFLU_OK;
+    };
+    const unsigned long long gbase = h->gate_epoch;
+    h->gate_epoch += (unsigned long long)nleaf + 2;
+    const unsigned long long wbase = h->gate_epoch;
+    h->gate_epoch += (unsigned long long)nblk + 2;
+    auto val = [&](int64_t g) { return gbase + (unsigned long long)g + 1; };
+    auto wval = [&](int64_t b) { return wbase + (unsigned long long)b + 1; };
+    int64_t gfirst = -1;        // first leaf factored leaf-wise (the gates of earlier leaves are never published)
+    bool prev_rec = false;      // the previous block column was factored by the recursion (its window belongs to S)
+    for (int64_t b = b_begin; b < nblk; ++b) {
+        const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
+        const int64_t bend = std::min(j0 + W, n), wend = std::min(j0 + 2 * W, n);
+        const bool leaf_mode = is_leaf_mode(b);
+        const int64_t g0 = j0 / NB, nl = (jb + NB - 1) / NB, glast = g0 + nl - 1;
+        h->stream = P;
+        if (!leaf_mode) {
+            // ---- chain: Toledo recursion on the block column, interchanges confined to its own columns ----
+            f.sw_lo = j0;
+            f.sw_hi = je;
+            RFLU_TRY(f.rec(j0, je));
+            f.sw_lo = 0;
+            f.sw_hi = -1;
+            if (b == 0 && f.tail) {
+                RFLU_HIP(hipStreamWaitEvent(P, f.tail, 0));
+                f.tail = nullptr;
+            }
+            RFLU_TRY(record_on(P, evP(b)));
+            // ---- chain: block column b+1 (its earlier updates came from the window stream, or from U when it entered there) ----
+            if (je < n) {
+                LaswpGate pgate;
+                if (b > b_begin && prev_rec) {
+                    pgate.wait_flag = h->gates + 3;
+                    pgate.wait_val = wval(b - 1);
+                    pgate.info = h->info_dev;
+                } else if (b > 0) {
+                    RFLU_TRY(wait_on(P, evU1(b - 1)));
+                }
+                RFLU_TRY(advance(P, b, b + 1, b, b + 1, je, std::min(je + W, n), pgate));
+                if (b + 1 < ncb) a[b + 1] = sw[b + 1] = b + 1;
+            }
+            // ---- window stream: block column b on [b+2, b+1+dwin]; the column block that ENTERS the window comes from U and is
+            // touched last, so a late sweep holds up nothing the chain needs soon ----
+            const int64_t w0 = b + 2, w1 = std::min(b + 2 + dwin, ncb);
+            RFLU_TRY(wait_on(S, evP(b)));
+            const bool entering = b > b_begin && w1 > w0 && w1 - 1 == b + 1 + dwin;
+            const int64_t wmid = entering ? w1 - 1 : w1;
+            auto publish = [&]() -> int {   // block column b+2 is ready for the chain
+                h->stream = S;
+                const int rc = launch_gate_signal(h, h->gates + 3, wval(b));
+                h->stream = P;
+                return rc;
+            };
+            if (wmid > w0) {
+                RFLU_TRY(advance(S, b, b + 1, b, b + 1, w0 * W, std::min(wmid * W, n)));
+                RFLU_TRY(publish());
+            }
+            if (entering) {
+                RFLU_TRY(wait_on(S, evU1(b - 1)));   // U's required update of the previous sweep
+                RFLU_TRY(advance(S, b, b + 1, b, b + 1, wmid * W, std::min(w1 * W, n)));
+            }
+            if (wmid <= w0) RFLU_TRY(publish());
+            for (int64_t c = w0; c < w1; ++c) a[c] = sw[c] = b + 1;
+            RFLU_TRY(record_on(S, evS(b)));
+        } else {
+            // ---- chain: leaf by leaf (factor_leafwise) ----
+            if (gfirst < 0) gfirst = g0;
+            if (b == 0 && f.tail) {
+                RFLU_HIP(hipStreamWaitEvent(P, f.tail, 0));
+                f.tail = nullptr;
+            }
+            for (int64_t i = 0; i < nl; ++i) {
+                const int64_t g = g0 + i, c0 = j0 + i * NB, w = std::min<int64_t>(NB, je - c0);
+                RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, f.ipiv, f.pivot));
+                const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);
+                const unsigned long long* wflag = nullptr;   // leaf g-1 reached LA through the side stream: its own block's part, or the next block's
+                if (la1 > la0 && g > gfirst) wflag = h->gate_ptr[la0 < std::min(((c0 - NB) / W + 1) * W, n) ? 1 : 2];
+                if (f.pivot && fold) {
+                    LaswpGate gt;
+                    gt.wait_flag = wflag;
+                    gt.wait_val = wflag ? val(g - 1) : 0;
+                    gt.signal_flag = h->gate_ptr[0];
+                    gt.signal_val = val(g);
+                    gt.signal_cnt = reinterpret_cast<unsigned*>(h->gates + 4);
+                    gt.info = h->info_dev;
+                    RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0), gt));
+                } else {
+                    if (wflag) RFLU_TRY(launch_gate_wait(h, wflag, val(g - 1)));
+                    if (f.pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0)));
+                    RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g)));
+                }
+                RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
+                // ---- side stream: leaf g on the rest of this block column and on the next one ----
+                h->stream = S;
+                int rc = launch_gate_wait(h, h->gate_ptr[0], val(g));
+                if (i == 0 && b > 0 && !(b > b_begin && prev_rec)) {
+                    // the next block column holds the earlier block columns' updates only after U's required update of the last
+                    // sweep; the chain needs this block column's part first: two pieces with a gate of its own in between
+                    if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, la1, bend, true);
+                    h->stream = S;
+                    if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g));
+                    if (rc == RFLU_OK) rc = wait_on(S, evU1(b - 1));
+                    if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, std::max(la1, bend), wend, true);
+                    h->stream = S;
+                    if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[2], val(g));
+                } else {
+                    if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, la1, wend, true);
+                    h->stream = S;
+                    if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g));
+                    if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[2], val(g));
+                }
+                h->stream = P;
+                RFLU_TRY(rc);
+            }
+            if (b + 1 < ncb) a[b + 1] = sw[b + 1] = b + 1;
+            RFLU_TRY(record_on(S, evS(b)));
+            // U goes on when the side stream has applied the last leaf
+            h->stream = U;
+            const int rcw = launch_gate_wait(h, h->gate_ptr[2], val(glast));
+            h->stream = P;
+            RFLU_TRY(rcw);
+        }
+        // ---- U: sweep(b).  First the interchanges of block column b on everything finished (all of L stays in the current row
+        // order); the side stream's last reads of L in the previous order must be over (its window update of block column b-1)
+        if (!leaf_mode) RFLU_TRY(wait_on(U, evP(b)));
+        if (b > b_begin && prev_rec) RFLU_TRY(wait_on(U, evS(b - 1)));
+        if (f.pivot) {
+            hipStream_t saved = h->stream;
+            h->stream = U;
+            int rc = RFLU_OK;
+            if (leaf_mode)
+                for (int64_t i = 0; i + 1 < nl && rc == RFLU_OK; ++i)   // leaf i's columns: the later leaves' interchanges
+                    rc = launch_laswp<T>(h, R, ld, j0 + i * NB, NB, g0 + i + 1, g0 + nl);
+            if (rc == RFLU_OK && j0 > 0) rc = launch_laswp<T>(h, R, ld, 0, j0, g0, g0 + nl);
+            h->stream = saved;
+            RFLU_TRY(rc);
+        }
+        const double period = chain_us(b + 1);
+        tE += chain_us(b);
+        tU = std::max(tU, tE);
+        const bool last = b + 1 >= nblk;
+        const bool next_leaf = b + 1 < nblk && is_leaf_mode(b + 1);
+        const int64_t rs = b + 2 + (leaf_mode ? 0 : dwin);
+        RFLU_TRY(sweep(b, rs, (next_leaf ? scale_leaf : scale_rec) * (tE + period - tU), last));
+        RFLU_TRY(record_on(U, evUend(b)));
+        prev_rec = !leaf_mode;
+    }
+    h->stream = P;
+    RFLU_TRY(wait_on(P, evUend(nblk - 1)));
+    RFLU_TRY(wait_on(P, evS(nblk - 1)));
+    return RFLU_OK;
+}
+
 // Factor the row-major m x n matrix R in place (see rflu.h for `blocksize`).
 template <typename T>
 static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* ipiv, int pivot, int64_t blocksize,
@@ -864,6 +1205,9 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     if (mn == 0) return RFLU_OK;
     RFLU_TRY(ensure_bookkeeping(h, m));
     RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), h->stream));
+    // the wrapping "last workgroup" counters of the folded gates: a factorization that timed out or was aborted may have left
+    // them mid-count, and a stale count would publish the next factorization's gate early or never
+    RFLU_HIP(hipMemsetAsync(h->gates + 4, 0, 2 * sizeof(unsigned long long), h->stream));
     if (!pivot && ipiv) RFLU_TRY(launch_iota_ipiv(h, ipiv, 0, mn));  // src/lu.jl:111-113
 
     Fact<T> f{h, R, ld, m, n, ipiv, pivot};
@@ -896,6 +1240,12 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             told = true;
             leafwise = 0;
         }
+        {   // the leaf-wise / deep schedules hand work between streams through device-side gates: only with real CU-masked streams
+            hipStream_t probe;
+            RFLU_TRY(get_ustream(h, 32, &probe));
+            RFLU_TRY(get_ustream(h, 64, &probe));
+            if (h->mask_failed) leafwise = 0;
+        }
         const int64_t Wb = round_up(blocksize, NB);
         const auto t_enq0 = std::chrono::steady_clock::now();
         const int64_t nblk = (mn + Wb - 1) / Wb;
@@ -911,13 +1261,29 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             b_switch = m <= lw_rows ? 0 : std::min(nblk, (m - lw_rows + Wb - 1) / Wb);
         }
         hipStream_t U_last = nullptr;
-        if (tail && b_switch == 0) {
-            RFLU_HIP(hipStreamWaitEvent(h->stream, tail, 0));
-            tail = nullptr;
+        // Deep lookahead (factor_deep, RFLU_DEEP=1) wherever the panel fits the 32 reserved CUs (<= 16384 rows) and the block
+        // columns are leaf-wise capable; taller block columns keep factor_lookahead.  Opt-in: measured (round 3, N=16384 Float64)
+        // 82.7-84 ms against 83.6 ms for the round-2 pair of schedules -- the update side (GEMM at its in-schedule rate plus its
+        // interchanges / solves / the leaf-wise K=64 updates) is ~80 ms of work on the masked CUs however it is ordered, so
+        // overlapping it better with the pivot chain buys nothing until that work gets cheaper.
+        static const bool deep_on = [] { const char* e = getenv("RFLU_DEEP"); return e != nullptr && atoi(e) != 0; }();
+        if (deep_on && leafwise && Wb >= 2 * NB && Wb <= 512) {
+            const int64_t deep_rows = 32 * (int64_t)PANEL_THREADS;
+            const int64_t b_deep = m <= deep_rows ? 0 : std::min(nblk, (m - deep_rows + Wb - 1) / Wb);
+            int64_t lw_rows = sizeof(T) == 8 ? 8192 : 16384;
+            if (const char* e = getenv("RFLU_LEAFWISE_ROWS")) lw_rows = atoll(e);
+            f.tail = tail;
+            if (b_deep > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_deep, &U_last));
+            if (b_deep < nblk) RFLU_TRY(factor_deep<T>(f, Wb, b_deep, U_last, lw_rows));
+        } else {
+            if (tail && b_switch == 0) {
+                RFLU_HIP(hipStreamWaitEvent(h->stream, tail, 0));
+                tail = nullptr;
+            }
+            f.tail = tail;
+            if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last));
+            if (b_switch < nblk) RFLU_TRY(factor_leafwise<T>(f, Wb, b_switch, U_last));
         }
-        f.tail = tail;
-        if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last));
-        if (b_switch < nblk) RFLU_TRY(factor_leafwise<T>(f, Wb, b_switch, U_last));
         if (getenv("RFLU_TIME_ENQUEUE"))
             fprintf(stderr, "[rflu] host enqueue time %.2f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count());
@@ -986,6 +1352,12 @@ static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int6
         RFLU_TRY(launch_transpose<T>(h, m, n, A, lda, R, ldr));
     }
     const int rc_f = getrf_rm<T>(h, m, n, R, ldr, ipiv, pivot, blocksize, info);
+    if (h->tail_event_obj && rc_f != RFLU_OK) {
+        // error before the tail event was consumed: the layout change may still be reading A / writing the workspace on the
+        // update stream -- do not hand either back to the caller while it runs
+        hipStream_t U0 = nullptr;
+        if (get_ustream(h, 32, &U0) == RFLU_OK && U0) (void)hipStreamSynchronize(U0);
+    }
     h->tail_event = nullptr;
     RFLU_TRY(rc_f);
     RFLU_TRY(launch_transpose<T>(h, n, m, R, ldr, A, lda));
@@ -1037,24 +1409,25 @@ namespace rflu { int get_ustream(Handle* h, int reserve, hipStream_t* out); }
 // tensors on several GPUs must not find its current device changed by a library call).
 struct DeviceGuard {
     int prev = -1;
-    bool switched = false;
     hipError_t err = hipSuccess;
     explicit DeviceGuard(int dev)
     {
         err = hipGetDevice(&prev);
-        if (err == hipSuccess && prev != dev) {
-            err = hipSetDevice(dev);
-            switched = (err == hipSuccess);
-        }
+        if (err != hipSuccess) { prev = -1; return; }
+        if (prev != dev) err = hipSetDevice(dev);
     }
+    // Restores UNCONDITIONALLY: the multi-GPU entry points switch devices inside loops after the guard was taken, so "did the
+    // constructor switch?" says nothing about where the current device is when the function returns (or bails out early).
     ~DeviceGuard()
     {
-        if (switched) (void)hipSetDevice(prev);
+        if (prev >= 0) (void)hipSetDevice(prev);
     }
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+// CHECK_HANDLE declares the guard object in the enclosing scope: it must be the FIRST statement of a function body (not the
+// body of an unbraced if / else, not twice in one scope).
 #define CHECK_HANDLE(h)                                  \
     if ((h) == nullptr) {                                \
         set_error("null handle");                        \

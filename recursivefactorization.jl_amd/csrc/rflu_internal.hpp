@@ -51,6 +51,8 @@ struct Handle {
     // second stream for the lookahead driver: the deferred trailing updates run here, restricted by a CU mask to
     // 224 of the 256 CUs so that the cooperative panel kernels of the critical path always find 32 free CUs
     hipStream_t ustreams[8] = {};     // ustreams[r]: CU mask leaving 32*r CUs to the critical path (r = 1..7)
+    bool mask_failed = false;         // a CU-masked stream could not be created: plain streams may share a hardware queue, so the
+                                      // device-side gates (which need the streams to run concurrently) are not used
     hipStream_t pstreams[8] = {};     // pstreams[r]: the complement -- exactly those 32*r CUs (critical path of the update-bound phase)
     bool panel_attr_set[2][2] = {};        // [Float64|Float32][64|128 rows]: dynamic-LDS attribute of the small-workgroup leaves
     hipEvent_t tail_event = nullptr;       // column-major entry: the columns right of the first block column are still being

@@ -5,7 +5,7 @@ os.environ.setdefault("RFLU_PANEL_LOCAL", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from recursivefactorization.jl_amd import _ffi
-_ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), "librflu_trace.so")
+_ffi.LIB_PATH = os.environ.get("RFLU_TRACE_LIB") or os.path.join(_ffi.HERE, "librflu_trace.so")
 lib = _ffi.load()
 lib.rflu_debug_panel_trace.restype = ctypes.c_int
 lib.rflu_debug_panel_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

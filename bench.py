@@ -249,12 +249,16 @@ def main():
                     mg = MultiGPU([0] * world if one_gpu else list(range(world)))
                     slabs, lds, mlayout = mg.alloc(n, tdt, args.block, run)
                     ok[0] = 1
-                except Exception as exc:  # noqa: BLE001 -- reported, then the python driver takes over
-                    print(f"bench: multi-GPU C entry unavailable ({exc}); using the torch.distributed driver", file=sys.stderr)
+                except Exception as exc:  # noqa: BLE001 -- reported below, on every rank
+                    print(f"bench: multi-GPU C entry unavailable on rank 0: {exc}", file=sys.stderr)
                     mg = None
             dist.broadcast(ok, src=0)
             if int(ok.item()) != 1:
-                mgpu_mode = "python"
+                # No silent change of what is measured: the C entry needs rank 0 to see all N devices (and librccl.so).  The
+                # one-process-per-GPU torch.distributed driver is a different schedule; it runs only when asked for by name.
+                raise SystemExit(f"bench.py --gpus {world}: rank 0 could not set up the multi-GPU C entry "
+                                 f"(visible devices: {torch.cuda.device_count()}); set RFLU_BENCH_MGPU=python to time the "
+                                 "torch.distributed driver instead")
         if mgpu_mode == "c":
             mg_info = [0]
 

@@ -31,7 +31,7 @@ const HANDLE_LOCK = ReentrantLock()
 "below this many columns the CPU recursion wins (PCIe staging + launch latency); `ENV[\"RFLU_MIN_N\"]` overrides"
 const GPU_MIN_N = Ref{Int}(parse(Int, get(ENV, "RFLU_MIN_N", "1024")))
 "Julia >= 1.11 reports NoPivot failures with a negative info (RecursiveFactorization src/lu.jl:25)"
-const NOPIVOT_NEGATIVE_INFO = VERSION >= v"1.11.0-DEV.1535"
+const NOPIVOT_NEGATIVE_INFO = VERSION >= v"1.11.0-DEV"   # as src/lu.jl:25
 
 # rflu_status (include/rflu.h)
 const RFLU_OK = Cint(0)
@@ -190,7 +190,11 @@ end
 
 "solve with the factors on the GPU when they are large enough, else stdlib `ldiv!`"
 function ldiv!(F::LU{T, <:StridedMatrix{T}}, B::StridedVecOrMat{T}) where {T <: GPUEltype}
-    if size(F.factors, 1) >= GPU_MIN_N[] && available() && (F.ipiv isa Vector{Int64} || F.ipiv isa NotIPIV)
+    # the same layout conditions as `gpu_ok` for lu!: getrs! passes stride(F, 2) / stride(B, 2) as leading dimensions, i.e. it
+    # assumes unit row stride and a square factorization; anything else (a strided view, an LU from a non-unit-stride CPU
+    # fallback, a B with the wrong number of rows) stays with the stdlib
+    lay_ok = stride(F.factors, 1) == 1 && stride(B, 1) == 1 && size(F.factors, 1) == size(F.factors, 2) == size(B, 1)
+    if lay_ok && size(F.factors, 1) >= GPU_MIN_N[] && available() && (F.ipiv isa Vector{Int64} || F.ipiv isa NotIPIV)
         p = F.ipiv isa NotIPIV ? Ptr{Int64}(C_NULL) : pointer(F.ipiv)
         GC.@preserve F B getrs!(F.factors, p, B)
         return B

@@ -14,6 +14,7 @@ from .oracle import (  # noqa: F401
     lu,
     np_uniform,
     nsplit,
+    perm_from_ipiv,
     residual,
     set_threads,
     unpack_lu,

@@ -29,7 +29,10 @@ from .butterfly import (  # noqa: F401,E402
     butterfly_workspace,
 )
 
+from . import linsolve  # noqa: F401,E402  (LinearSolve.jl's RFLUFactorization cache protocol)
+
 __all__ = [
+    "linsolve",
     "ButterflyWorkspace", "butterfly_workspace", "butterfly_solve_", "butterfly_mul_",
     "lu", "lu_", "ldiv_", "LU", "NotIPIV", "RowMaximum", "NoPivot", "Val", "Adjoint", "Transpose", "SingularException",
     "normalize_pivot", "last_path", "Handle", "RfluError", "default_handle", "NOPIVOT_NEGATIVE_INFO",

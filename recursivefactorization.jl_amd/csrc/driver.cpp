@@ -37,6 +37,18 @@ void set_error(const char* fmt, ...)
 
 static int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Leading dimension of the row-major workspace for n columns: a multiple of 16 elements (rows start on 128-byte lines).
+// RFLU_LD_PAD=<elements> adds a padding when that is a multiple of 512 elements (a power-of-two row pitch): measured on MI355X
+// (round 3, N=16384: 82.7 ms / laswp 3.11 TB/s without, 82.3-82.9 ms / 3.0-3.17 TB/s with 16..272 elements) it changes nothing --
+// the HBM address hash already spreads equal columns of consecutive rows over the channels -- so the default is none.
+static int64_t workspace_ld(int64_t n)
+{
+    static const int64_t pad = [] { const char* e = getenv("RFLU_LD_PAD"); return e ? (atoll(e) / 16) * 16 : 0ll; }();
+    int64_t ld = round_up(std::max<int64_t>(n, 1), 16);
+    if (pad > 0 && ld % 512 == 0) ld += pad;
+    return ld;
+}
+
 int ensure_buffer(void** ptr, size_t* cap, size_t need)
 {
     if (*cap >= need) return RFLU_OK;
@@ -153,7 +165,7 @@ static int getrs_cm_dev(Handle* h, int64_t n, int64_t nrhs, const T* F, int64_t 
         return RFLU_ERR_ARG;
     }
     if (n == 0 || nrhs == 0) return RFLU_OK;
-    const int64_t ldr = round_up(n, 16), ldx = round_up(nrhs, 16);
+    const int64_t ldr = workspace_ld(n), ldx = round_up(nrhs, 16);
     RFLU_TRY(ensure_buffer(&h->work, &h->work_bytes, (size_t)n * (size_t)ldr * sizeof(T)));
     RFLU_TRY(ensure_buffer(&h->rhs_work, &h->rhs_work_bytes, (size_t)n * (size_t)ldx * sizeof(T)));
     T* R = static_cast<T*>(h->work);
@@ -1323,7 +1335,7 @@ static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int6
     }
     *info = 0;
     if (m == 0 || n == 0) return RFLU_OK;
-    const int64_t ldr = round_up(n, 16);
+    const int64_t ldr = workspace_ld(n);
     RFLU_TRY(ensure_buffer(&h->work, &h->work_bytes, (size_t)m * (size_t)ldr * sizeof(T)));
     T* R = static_cast<T*>(h->work);
     // Layout change in two pieces: the first block column on the caller's stream, the rest on the CU-masked update stream while
@@ -1891,7 +1903,7 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
             RFLU_HIP(hipMalloc((void**)&g->ipiv[d], (size_t)n * sizeof(int64_t)));
             g->ipiv_cap[d] = (size_t)n;
         }
-        if (!g->U[d]) RFLU_TRY(get_ustream(h, 32, &g->U[d]));
+        RFLU_TRY(get_ustream(h, 32, &g->U[d]));   // the update stream a device starts on (the mask leaves 32 CUs to the panel)
         g->P[d] = h->own_stream;
         h->last_path = RFLU_PATH_HIP_LOOKAHEAD;
         // start state on both streams of the device
@@ -1981,11 +1993,17 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
     };
 
     RFLU_TRY(produce(0));
-    // a panel taller than this cannot run next to the bulk update (its cooperating workgroups need more CUs than the update
-    // stream's mask leaves free): its owner factors it BEFORE its own bulk update and catches up afterwards, while the
-    // other devices are already applying it
-    int64_t tall_rows = 32 * (int64_t)PANEL_THREADS;
+    // The NEXT owner factors block column b+1 next to its own share of update b, which is only 1/D of the bulk: it can afford
+    // to leave the panel as many CUs as its cooperating workgroups need.  Up to 32 workgroups (16384 rows): the usual 32-CU
+    // reservation; up to `big_reserve` CUs (default 128 = 65536 rows): that device runs update b on the update stream of the big
+    // reservation (ONE extra stream per device: panel stream, 32-CU mask, big mask -- the fourth queue costs 25 %, DESIGN.md
+    // "queues").  Only a panel that needs even more is factored BEFORE the owner's bulk update (round 2 did that from 16384
+    // rows on: at N=65536 over 8 GPUs 96 of 128 block columns, ~0.3 s of un-overlapped panels).
+    int64_t big_reserve = 128;
+    if (const char* e = getenv("RFLU_MGPU_BIG_RESERVE")) big_reserve = std::min<int64_t>(224, std::max<int64_t>(0, atoll(e) / 32 * 32));
+    int64_t tall_rows = std::max<int64_t>(32, big_reserve) * (int64_t)PANEL_THREADS;
     if (const char* e = getenv("RFLU_MGPU_TALL_ROWS")) tall_rows = atoll(e);     // debugging knobs
+    std::vector<hipStream_t> Ucur(g->U);   // the stream that carried each device's previous update
     const int dbg_sync = getenv("RFLU_MGPU_SYNC") ? atoi(getenv("RFLU_MGPU_SYNC")) : 0;
     auto sync_all = [&]() -> int {
         for (int d = 0; d < D; ++d) { RFLU_HIP(hipSetDevice(g->devs[d])); RFLU_HIP(hipDeviceSynchronize()); }
@@ -1999,16 +2017,32 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
         const bool tall_next = nxt_owner >= 0 && (n - lay[b + 1].j0) > tall_rows;
         std::vector<int64_t> left_end(D, 0), right_start(D, 0), nxt_slice(D, 0);
         hipEvent_t e;
+        // the update stream of every device for this block column: the next owner leaves its panel the CUs it needs
+        std::vector<hipStream_t> Ub(g->U);
+        if (nxt_owner >= 0 && !tall_next && D > 1) {
+            const int64_t gw = panel_wgs(g->h[nxt_owner], n - lay[b + 1].j0, pivot);
+            if (gw > 32 && big_reserve > 32) {
+                RFLU_HIP(hipSetDevice(g->devs[nxt_owner]));
+                RFLU_TRY(get_ustream(g->h[nxt_owner], (int)big_reserve, &Ub[nxt_owner]));
+            }
+        }
+        for (int d = 0; d < D; ++d) {
+            if (Ub[d] == Ucur[d]) continue;   // a different mask = a different stream: order it behind the device's last update
+            RFLU_HIP(hipSetDevice(g->devs[d]));
+            if (b >= 1) RFLU_TRY(EV(d, b - 1, 2, &e)); else RFLU_TRY(mgpu_event(g, d, 0, &e));
+            RFLU_HIP(hipStreamWaitEvent(Ub[d], e, 0));
+            Ucur[d] = Ub[d];
+        }
         // ---- phase 1: receive, pivots, and the slice of the next owner
         for (int d = 0; d < D; ++d) {
             RFLU_HIP(hipSetDevice(g->devs[d]));
             Handle* h = g->h[d];
-            h->stream = g->U[d];
+            h->stream = Ub[d];
             RFLU_TRY(EV(d, b, 0, &e));                       // packed (owner) / received (others)
-            RFLU_HIP(hipStreamWaitEvent(g->U[d], e, 0));
+            RFLU_HIP(hipStreamWaitEvent(Ub[d], e, 0));
             const T* pb = static_cast<const T*>(g->pbuf[par][d]);
             if (d != c.owner)
-                RFLU_HIP(hipMemcpyAsync(g->ipiv[d] + c.j0, g->meta[par][d], (size_t)c.w * sizeof(int64_t), hipMemcpyDeviceToDevice, g->U[d]));
+                RFLU_HIP(hipMemcpyAsync(g->ipiv[d] + c.j0, g->meta[par][d], (size_t)c.w * sizeof(int64_t), hipMemcpyDeviceToDevice, Ub[d]));
             if (pivot) RFLU_TRY(launch_perm_build(h, g->ipiv[d], c.j0, c.j0 + c.w, n));
             for (int64_t q = 0; q < b; ++q) if (lay[q].owner == d) left_end[d] += lay[q].w;
             right_start[d] = left_end[d] + (d == c.owner ? c.w : 0);
@@ -2017,27 +2051,27 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
                 RFLU_TRY(mgpu_update<T>(h, n, slabs[d], lds[d], pb, c.j0, c.w, right_start[d], nxt_slice[d], pivot));
             }
             RFLU_TRY(EV(d, b, 1, &e));
-            RFLU_HIP(hipEventRecord(e, g->U[d]));
+            RFLU_HIP(hipEventRecord(e, Ub[d]));
         }
         if (dbg_sync & 2) RFLU_TRY(sync_all());
         if (tall_next) {
             RFLU_TRY(produce(b + 1));
             RFLU_HIP(hipSetDevice(g->devs[nxt_owner]));
             RFLU_TRY(EV(nxt_owner, b + 1, 0, &e));
-            RFLU_HIP(hipStreamWaitEvent(g->U[nxt_owner], e, 0));
+            RFLU_HIP(hipStreamWaitEvent(Ub[nxt_owner], e, 0));
         }
         // ---- phase 2: interchanges on the finished columns to the left, bulk update of the rest
         for (int d = 0; d < D; ++d) {
             RFLU_HIP(hipSetDevice(g->devs[d]));
             Handle* h = g->h[d];
-            h->stream = g->U[d];
+            h->stream = Ub[d];
             const T* pb = static_cast<const T*>(g->pbuf[par][d]);
             if (pivot && left_end[d] > 0)
                 RFLU_TRY(launch_laswp<T>(h, slabs[d], lds[d], 0, left_end[d], c.j0 / NB, (c.j0 + c.w + NB - 1) / NB));
             RFLU_TRY(mgpu_update<T>(h, n, slabs[d], lds[d], pb, c.j0, c.w, right_start[d] + nxt_slice[d],
                                     ncols_loc[d] - right_start[d] - nxt_slice[d], pivot));
             RFLU_TRY(EV(d, b, 2, &e));
-            RFLU_HIP(hipEventRecord(e, g->U[d]));
+            RFLU_HIP(hipEventRecord(e, Ub[d]));
         }
         if (b + 1 < nb && !tall_next) RFLU_TRY(produce(b + 1));   // queued behind the slice update: overlaps with the bulk of update b
     }
@@ -2048,6 +2082,7 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
         Handle* h = g->h[d];
         RFLU_HIP(hipStreamSynchronize(g->P[d]));
         RFLU_HIP(hipStreamSynchronize(g->U[d]));
+        if (Ucur[d] != g->U[d]) RFLU_HIP(hipStreamSynchronize(Ucur[d]));
         RFLU_HIP(hipMemcpy(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost));
         if (h->info_pinned[0] != 0 && (first == 0 || h->info_pinned[0] < first)) first = h->info_pinned[0];
         flags |= h->info_pinned[1];

@@ -3,97 +3,96 @@
 // apply_permutation! (/root/reference/src/lu.jl:164-188) swaps row i with row P[i] sequentially for every pivot of a
 // block.  Here a chunk of up to 64 sequential interchanges has already been folded (panel.hip: perm_build_wave) into an
 // equivalent list of at most 128 independent row MOVES  new[dst[e]] = old[src[e]], so the kernel is a pure gather /
-// scatter of contiguous row segments in the row-major R layout: each wave reads 64 consecutive columns (512 B for
-// Float64) of a source row, all reads of a chunk are issued before the first write (one barrier), and every pivot
-// costs exactly its algorithmic 4*sizeof(T) bytes per column of HBM traffic -- no cache-line amplification.
+// scatter of contiguous row segments in the row-major R layout: a wave owns a strip of columns (one 128-byte line per row),
+// issues all row reads of a chunk before the first write, and every pivot costs exactly its algorithmic 4*sizeof(T) bytes
+// per column of HBM traffic -- no cache-line amplification.
 // Roofline: HBM (8 TB/s spec, ~6.3 TB/s achievable); algorithmic bytes per launch = 4*sizeof(T)*ncols*pivots.
+#include <stdint.h>
 #include "rflu_internal.hpp"
 #include "trsm_row.hpp"
 
 namespace rflu {
 
-constexpr int LW_COLS = 16;           // columns per workgroup: 16 lanes x 8 bytes = one 128-byte line of every row it touches
-constexpr int LW_RSUB = 64 / LW_COLS; // row slots per wave (a wave covers 4 rows x 16 columns per access)
-constexpr int LW_ROWS_PER_THREAD = (2 * NB) / (4 * LW_RSUB);  // 4 waves x 4 row slots share the <=128 moves of a chunk
+// Geometry (round 3).  A row segment is 8 lanes x 16 bytes = one 128-byte line (16 Float64 / 32 Float32 columns); a wave holds 8
+// row slots, so the <= 128 moves of a chunk are 16 independent 16-byte loads per lane, ALL in flight before the first store
+// (16 KB per wave).  Every WAVE owns its column strip for all chunks of the launch: loads and stores of one wave to the same
+// address stay in program order, so there is no workgroup barrier anywhere (round 2: two __syncthreads per chunk, 8-byte
+// accesses, and 64 KB of static LDS in every workgroup -- 2 workgroups per CU -- for the one workgroup that inverts a diagonal
+// block).  The next chunk's move list is requested before the current chunk's rows are stored.  VW = 1 is the same kernel with
+// one element per lane for column ranges that are not 16-byte aligned.
+constexpr int LW_WAVES = 4;                   // independent waves per workgroup
 
-template <typename T>
-__device__ __forceinline__ void laswp_body(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1,
-                                           int64_t ncolsB, int64_t c2, int64_t ncolsC, const int* __restrict__ pm_cnt,
-                                           const int* __restrict__ pm_dst, const int* __restrict__ pm_src, int chunk0,
-                                           int chunk1, int inv_nb, int inv_cnt, const T* inv_L, T* inv_out, T* sL, T* sX)
+template <typename T, int VW, int LW_LPR>
+__device__ __forceinline__ void laswp_strip(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1,
+                                            int64_t ncolsB, int64_t c2, int64_t ncolsC, const int* __restrict__ pm_cnt,
+                                            const int* __restrict__ pm_dst, const int* __restrict__ pm_src, int chunk0,
+                                            int chunk1, int64_t strip)
 {
+    constexpr int LW_RS = 64 / LW_LPR;        // row slots per wave
+    constexpr int LW_NI = (2 * NB) / LW_RS;   // loads per lane and chunk (at most)
+    constexpr int SC = LW_LPR * VW;           // columns per strip
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t blocksA = (ncolsA + LW_COLS - 1) / LW_COLS;
-    const int64_t blocksB = (ncolsB + LW_COLS - 1) / LW_COLS;
-    const int64_t blocksC = (ncolsC + LW_COLS - 1) / LW_COLS;
-    if ((int64_t)blockIdx.x >= blocksA + blocksB + blocksC) {
-        const int64_t i = (int64_t)blockIdx.x - (blocksA + blocksB + blocksC);
-        if (inv_nb > 0 && i < inv_cnt)   // workgroup-uniform
-            diag_inv_block4<T>(inv_nb, inv_L + i * (NB * ld + NB), ld, inv_out + i * NB * NB, sL, sX, threadIdx.x);
-        return;
-    }
-    // the column ranges are covered by one launch (left and right of a panel, and a pair's first leaf)
-    const int cl = lane & (LW_COLS - 1), rsub = lane / LW_COLS;
-    int64_t col;
-    bool active;
+    const int64_t stripsA = (ncolsA + SC - 1) / SC, stripsB = (ncolsB + SC - 1) / SC;
+    const int cl = lane & (LW_LPR - 1), rsub = lane / LW_LPR;
+    int64_t col, off, lim;
     int first = chunk0;
-    if ((int64_t)blockIdx.x < blocksA) {
-        const int64_t off = (int64_t)blockIdx.x * LW_COLS + cl;
-        col = c0 + off;
-        active = off < ncolsA;
-    } else if ((int64_t)blockIdx.x < blocksA + blocksB) {
-        const int64_t off = ((int64_t)blockIdx.x - blocksA) * LW_COLS + cl;
-        col = c1 + off;
-        active = off < ncolsB;
+    if (strip < stripsA) {
+        off = strip * SC + cl * VW; col = c0 + off; lim = ncolsA;
+    } else if (strip < stripsA + stripsB) {
+        off = (strip - stripsA) * SC + cl * VW; col = c1 + off; lim = ncolsB;
     } else {
-        const int64_t off = ((int64_t)blockIdx.x - blocksA - blocksB) * LW_COLS + cl;
-        col = c2 + off;
-        active = off < ncolsC;
+        off = (strip - stripsA - stripsB) * SC + cl * VW; col = c2 + off; lim = ncolsC;
         first = chunk0 + 1;
     }
-    const int ebase = wave * LW_RSUB + rsub;   // this thread's moves: ebase, ebase + 16, ...
-    T v[LW_ROWS_PER_THREAD];
+    const bool active = off < lim;   // whole vectors only: the launcher picks VW = 1 unless every range is a multiple of VW
+    if (first >= chunk1) return;
+    int cnt = pm_cnt[first];
+    int s0 = pm_src[(size_t)first * 2 * NB + lane], s1 = pm_src[(size_t)first * 2 * NB + NB + lane];
+    int d0 = pm_dst[(size_t)first * 2 * NB + lane], d1 = pm_dst[(size_t)first * 2 * NB + NB + lane];
     for (int t = first; t < chunk1; ++t) {
-        // the whole move list of the chunk in four coalesced loads (lane e holds entries e and e+64) ...
-        const int cnt = pm_cnt[t];
-        const int s0 = pm_src[(size_t)t * 2 * NB + lane], s1 = pm_src[(size_t)t * 2 * NB + NB + lane];
-        const int d0 = pm_dst[(size_t)t * 2 * NB + lane], d1 = pm_dst[(size_t)t * 2 * NB + NB + lane];
-        // ... so that all row loads of the chunk are in flight together (one memory latency, not one per row)
-        int dst[LW_ROWS_PER_THREAD];
+        vec_t v[LW_NI];
+        int dst[LW_NI];
 #pragma unroll
-        for (int i = 0; i < LW_ROWS_PER_THREAD; ++i) {
-            const int e = ebase + 16 * i;   // < 128; the same for the 16 lanes of a row slot
-            const int src = (e < NB) ? __shfl(s0, e & 63) : __shfl(s1, e & 63);
-            dst[i] = (e < NB) ? __shfl(d0, e & 63) : __shfl(d1, e & 63);
-            if (e < cnt && active) v[i] = R[(int64_t)src * ld + col];
+        for (int i = 0; i < LW_NI; ++i) {
+            const int e = i * LW_RS + rsub;   // < 128; the same for the 8 lanes of a row slot
+            const int src = (i * LW_RS < NB) ? __shfl(s0, e & 63) : __shfl(s1, e & 63);
+            dst[i] = (i * LW_RS < NB) ? __shfl(d0, e & 63) : __shfl(d1, e & 63);
+            if (i * LW_RS < cnt) {   // wave-uniform
+                if (e < cnt && active) v[i] = *reinterpret_cast<const vec_t*>(R + (int64_t)src * ld + col);
+            }
         }
-        __syncthreads();
+        const int cur = cnt;
+        if (t + 1 < chunk1) {   // the next chunk's move list travels while this chunk's rows are still arriving
+            cnt = pm_cnt[t + 1];
+            s0 = pm_src[(size_t)(t + 1) * 2 * NB + lane];
+            s1 = pm_src[(size_t)(t + 1) * 2 * NB + NB + lane];
+            d0 = pm_dst[(size_t)(t + 1) * 2 * NB + lane];
+            d1 = pm_dst[(size_t)(t + 1) * 2 * NB + NB + lane];
+        }
 #pragma unroll
-        for (int i = 0; i < LW_ROWS_PER_THREAD; ++i) {
-            const int e = ebase + 16 * i;
-            if (e < cnt && active) R[(int64_t)dst[i] * ld + col] = v[i];
+        for (int i = 0; i < LW_NI; ++i) {
+            const int e = i * LW_RS + rsub;
+            if (i * LW_RS < cur) {
+                if (e < cur && active) *reinterpret_cast<vec_t*>(R + (int64_t)dst[i] * ld + col) = v[i];
+            }
         }
-        __syncthreads();
     }
 }
 
 // inv_nb > 0: extra workgroups (the last inv_cnt) invert the leaves' 64x64 diagonal blocks for the fused TRSMs that follow
-// (trsm.hip) -- they ride along with the leaf's interchange launch instead of costing a dependent launch of their own.
+// (trsm.hip) -- they ride along with the leaf's interchange launch instead of costing a dependent launch of their own; such a
+// launch asks for 2 * NB * NB elements of dynamic LDS, every other launch for none.
 // A third column range [c2, c2+ncolsC) receives only the chunks after the first: for a pair leaf (panel.hip) these are
 // leaf A's own columns, which still need leaf B's interchanges.
-// Geometry: narrow column strips (16 columns) give 4x the workgroups of a 64-column strip -- a full-width launch at N=16384
-// is ~1000 workgroups instead of 248 (less than one per CU), so four times as many row loads are in flight per dependent
-// {move list -> rows -> barrier -> stores} round of a chunk.
-template <typename T>
-__global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA,
-                                                    int64_t c1, int64_t ncolsB, int64_t c2, int64_t ncolsC,
-                                                    const int* __restrict__ pm_cnt, const int* __restrict__ pm_dst,
-                                                    const int* __restrict__ pm_src, int chunk0, int chunk1, int inv_nb,
-                                                    int inv_cnt, const T* inv_L, T* inv_out, LaswpGate gate)
+template <typename T, int VW, int LW_LPR>
+__global__ void __launch_bounds__(64 * LW_WAVES) laswp_kernel(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA,
+                                                              int64_t c1, int64_t ncolsB, int64_t c2, int64_t ncolsC,
+                                                              const int* __restrict__ pm_cnt, const int* __restrict__ pm_dst,
+                                                              const int* __restrict__ pm_src, int chunk0, int chunk1, int inv_nb,
+                                                              int inv_cnt, const T* inv_L, T* inv_out, LaswpGate gate)
 {
-    __shared__ T sL[NB * NB];
-    __shared__ T sX[NB * NB];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lw_smem[];
     if (gate.wait_flag) {   // folded stream gate (factor_leafwise): hold until another stream has passed `wait_val`
         if (threadIdx.x == 0) {
             const long long t0 = wall_clock64();
@@ -107,8 +106,20 @@ __global__ void __launch_bounds__(256) laswp_kernel(T* __restrict__ R, int64_t l
         }
         __syncthreads();
     }
-    laswp_body<T>(R, ld, c0, ncolsA, c1, ncolsB, c2, ncolsC, pm_cnt, pm_dst, pm_src, chunk0, chunk1, inv_nb, inv_cnt, inv_L,
-                  inv_out, sL, sX);
+    constexpr int SC = LW_LPR * VW;
+    const int64_t strips = (ncolsA + SC - 1) / SC + (ncolsB + SC - 1) / SC + (ncolsC + SC - 1) / SC;
+    const int64_t swap_blocks = (strips + LW_WAVES - 1) / LW_WAVES;
+    if ((int64_t)blockIdx.x >= swap_blocks) {
+        const int64_t i = (int64_t)blockIdx.x - swap_blocks;
+        if (inv_nb > 0 && i < inv_cnt) {   // workgroup-uniform
+            T* sL = reinterpret_cast<T*>(lw_smem);
+            diag_inv_block4<T>(inv_nb, inv_L + i * (NB * ld + NB), ld, inv_out + i * NB * NB, sL, sL + NB * NB, threadIdx.x);
+        }
+    } else {
+        const int64_t strip = (int64_t)blockIdx.x * LW_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (strip < strips)
+            laswp_strip<T, VW, LW_LPR>(R, ld, c0, ncolsA, c1, ncolsB, c2, ncolsC, pm_cnt, pm_dst, pm_src, chunk0, chunk1, strip);
+    }
     if (gate.signal_flag) {   // the last workgroup to get here publishes `signal_val` (the counter wraps back to zero)
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -134,15 +145,31 @@ int launch_laswp3(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64
     if (inv_nb <= 0) inv_cnt = 0;
     if (!swaps && inv_cnt <= 0 && !gate.wait_flag && !gate.signal_flag) return RFLU_OK;
     if (!swaps) { ncolsA = ncolsB = ncolsC = 0; }
-    int64_t blocks = (ncolsA + LW_COLS - 1) / LW_COLS + (ncolsB + LW_COLS - 1) / LW_COLS +
-                     (ncolsC + LW_COLS - 1) / LW_COLS + inv_cnt;
+    // 16-byte accesses when every column range starts and ends on a 16-byte boundary (ld is a multiple of 16 elements)
+    constexpr int VWF = 16 / (int)sizeof(T);
+    const bool vec = (reinterpret_cast<uintptr_t>(R) % 16 == 0) && ld % VWF == 0 &&
+                     (ncolsA == 0 || (c0 % VWF == 0 && ncolsA % VWF == 0)) && (ncolsB == 0 || (c1 % VWF == 0 && ncolsB % VWF == 0)) &&
+                     (ncolsC == 0 || (c2 % VWF == 0 && ncolsC % VWF == 0));
+    // lanes per row segment: 8 x 16 bytes = one 128-byte line (RFLU_LASWP_LPR=4: half-line segments, twice the waves -- measured
+    // no better: 2.97 vs 3.16 TB/s on the wide launches of an N=16384 factorization)
+    static const int lpr_env = [] { const char* e = getenv("RFLU_LASWP_LPR"); return e ? atoi(e) : 0; }();
+    const int lpr = lpr_env == 4 ? 4 : 8;
+    const int64_t SC = lpr * (vec ? VWF : 1);
+    const int64_t strips = (ncolsA + SC - 1) / SC + (ncolsB + SC - 1) / SC + (ncolsC + SC - 1) / SC;
+    int64_t blocks = (strips + LW_WAVES - 1) / LW_WAVES + inv_cnt;
     if (blocks == 0) blocks = 1;   // gates only: one idle workgroup (beyond every range, inv_cnt == 0)
     const double moved = 4.0 * sizeof(T) * (double)NB * ((double)(ncolsA + ncolsB) * (double)(chunk1 - chunk0) +
                                                          (double)ncolsC * (double)(chunk1 - chunk0 - 1));
     ProfScope ps(h, moved >= 32.0 * 1024 * 1024 ? RFLU_K_LASWP_WIDE : RFLU_K_LASWP, moved);
-    hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, h->stream, R, ld, c0, ncolsA, c1, ncolsB, c2,
-                       ncolsC, h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk0, (int)chunk1, (int)inv_nb, (int)inv_cnt, inv_L,
-                       inv_out, gate);
+    const size_t lds = inv_cnt > 0 ? 2 * (size_t)NB * NB * sizeof(T) : 0;
+#define RFLU_LASWP_LAUNCH(VWX, LPRX)                                                                                          \
+    hipLaunchKernelGGL((laswp_kernel<T, VWX, LPRX>), dim3((unsigned)blocks), dim3(64 * LW_WAVES), lds, h->stream, R, ld, c0,    \
+                       ncolsA, c1, ncolsB, c2, ncolsC, h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk0, (int)chunk1, (int)inv_nb, \
+                       (int)inv_cnt, inv_L, inv_out, gate)
+    if (vec && lpr == 4) RFLU_LASWP_LAUNCH(VWF, 4);
+    else if (vec) RFLU_LASWP_LAUNCH(VWF, 8);
+    else RFLU_LASWP_LAUNCH(1, 8);
+#undef RFLU_LASWP_LAUNCH
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }

@@ -81,3 +81,44 @@ def matvec_residual(A, LU, ipiv, chunk=4096, trials=2):
         r = torch.linalg.norm(ax[perm] - lz) / torch.linalg.norm(ax)
         worst = max(worst, float(r.item()))
     return worst
+
+
+def matvec_residual_slabs(n, slabs, layout, ipiv, seed=12, diag_add=0.0, trials=1):
+    """The same O(n^2) check for a factorization held as 1-D block-column slabs (row-major n x local columns per logical
+    device, layout = [(j0, w, owner, lc)]): ||P*A*x - L*(U*x)|| / ||A*x|| with A regenerated block column by block column from
+    the library's counter-based generator (nothing of size n x n is allocated besides the slabs themselves)."""
+    dev = slabs[0].device
+    dtype = np.float64 if slabs[0].dtype == torch.float64 else np.float32
+    ip = np.asarray(ipiv)
+    perm = np.arange(n)
+    for i, t in enumerate(ip):
+        j = int(t) - 1
+        if j != i:
+            perm[i], perm[j] = perm[j], perm[i]
+    perm = torch.from_numpy(perm).to(dev)
+    rows = torch.arange(n, device=dev)[:, None]
+    gen = torch.Generator(device="cpu").manual_seed(4321)
+    zero = torch.zeros((), dtype=torch.float64, device=dev)
+    worst = 0.0
+    for _ in range(trials):
+        x = torch.rand(n, dtype=torch.float64, generator=gen).to(dev)
+        ax = torch.zeros(n, dtype=torch.float64, device=dev)
+        ux = torch.zeros(n, dtype=torch.float64, device=dev)
+        for (j0, w, owner, lc) in layout:
+            blkA = torch.empty((w, n), dtype=tdtype(dtype), device=dev).T   # n x w, column-major
+            handle().call(f"rflu_fill_uniform_{sfx(dtype)}_dev", ptr(blkA), n, w, n, 0, seed, n, 0, j0, float(diag_add))
+            xb = x[j0:j0 + w]
+            ax += blkA.to(torch.float64) @ xb
+            cols = torch.arange(j0, j0 + w, device=dev)[None, :]
+            blk = slabs[owner][:, lc:lc + w].to(dev).to(torch.float64)
+            ux += torch.where(rows <= cols, blk, zero) @ xb
+            del blk, blkA
+        lz = ux.clone()   # unit diagonal of L
+        for (j0, w, owner, lc) in layout:
+            cols = torch.arange(j0, j0 + w, device=dev)[None, :]
+            blk = slabs[owner][:, lc:lc + w].to(dev).to(torch.float64)
+            lz += torch.where(rows > cols, blk, zero) @ ux[j0:j0 + w]
+            del blk
+        r = torch.linalg.norm(ax[perm] - lz) / torch.linalg.norm(ax)
+        worst = max(worst, float(r.item()))
+    return worst

@@ -93,3 +93,31 @@ def test_one_logical_device_and_layout_query():
     assert lib.rflu_mgpu_local_cols(1000, 100, 3, 1, 0) == 400   # block widths need not be multiples of 64 for the query
     assert lib.rflu_mgpu_local_cols(1000, 128, 3, 1, 5) == -1
     mg.close()
+
+
+# ---- BASELINE configs 3 and 4 in THEIR layout at FULL size (fake multi-GPU: k logical devices on the one GPU of the box) --------
+# "N=32768 Float64, 1-D block-column over 2 and 4 GPUs" and "N=65536 Float64 over 8": block 512, runs of 4 block columns per owner
+# (what bench.py --gpus N uses).  Checked like tests/test_gpu_configs.py: info, the O(n^2) mat-vec residual below the north
+# star's 1e-12, and ipiv equal to the 1-GPU factorization of the same generated matrix.
+@pytest.mark.parametrize("n,k", [(32768, 2), (32768, 4), (65536, 8)])
+def test_baseline_configs_3_4_in_their_layout_full_size(n, k, record_property):
+    from gpu_util import fill_uniform_cm, matvec_residual_slabs
+
+    block, run = 512, 4
+    mg = MultiGPU([0] * k)
+    slabs, lds, layout = mg.alloc(n, torch.float64, block, run)
+    mg.fill_uniform(n, slabs, lds, block, run, seed=12)
+    ipiv, info = mg.getrf(n, slabs, lds, block, run, pivot=True)
+    assert info == 0
+    res = matvec_residual_slabs(n, slabs, layout, ipiv, seed=12)
+    record_property("residual", res)
+    assert res < 1e-12, res
+    del slabs
+    mg.close()
+    torch.cuda.empty_cache()
+    A = fill_uniform_cm(n, np.float64, 12)
+    F = rf.lu_(A, None, True, check=False)
+    assert F.info == 0
+    assert np.array_equal(ipiv, F.ipiv.cpu().numpy()), "k-GPU pivots must equal the 1-GPU pivots"
+    del A, F
+    torch.cuda.empty_cache()

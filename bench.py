@@ -400,6 +400,71 @@ def main():
                 sweep.append({"blocksize": bs, "ms": round(1e3 * dt, 3), "gflops": round(flops / dt / 1e9, 1),
                               "frac_of_mfma_peak": round(flops / dt / 1e12 / PEAK_TFLOPS[sfx], 4)})
 
+    # ---- variants of the same workload (extra keys, never `value`): NoPivot, and the reference's butterfly route
+    # (src/butterflylu.jl:45-55): ONE pass A <- U'AV (HBM-bound), then lu!(A, Val(false)) -- no pivot search, hence no per-column
+    # latency chain -- and x = V ((U'AV) \ (U'b)) with the outer products as O(n) butterflies
+    variants = None
+    if single and not args.no_extras and pivot and args.blocksize == 0 and n % 4 == 0 and n >= 1024:
+        from recursivefactorization.jl_amd import butterfly as BF
+
+        esz = 8 if sfx == "f64" else 4
+        uv = torch.from_numpy(BF.generate_random(n, np.float64 if sfx == "f64" else np.float32, 888)).to(dev)
+        Acm = A.T   # the logical n x n matrix as a column-major view (stride(0) == 1) of the same memory
+
+        def step_np():
+            h.call(f"rflu_getrf_{sfx}_dev", n, n, ctypes.c_void_p(A.data_ptr()), n, ctypes.c_void_p(0), 0, 0, ctypes.byref(info))
+
+        def timed(fn, reps=3):
+            regenerate(); fn(); barrier()
+            tt0 = time.perf_counter()
+            for _ in range(reps):
+                regenerate()
+                fn()
+            barrier()
+            return (time.perf_counter() - tt0) / reps
+
+        def step_bf():
+            BF.butterfly_mul_(Acm, uv, handle=h)
+            step_np()
+
+        t_np = timed(step_np)
+        t_bf = timed(step_bf)
+        # the butterfly pass alone: HIP events on the launch stream (h runs on torch's current stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        regenerate(); barrier()
+        e0.record()
+        for _ in range(5):
+            BF.butterfly_mul_(Acm, uv, handle=h)
+        e1.record()
+        barrier()
+        bf_ms = e0.elapsed_time(e1) / 5
+        # backward error of the solve through the butterfly route (A x = b, b = A * ones)
+        regenerate(); barrier()
+        A0 = A.clone()
+        bvec = A0.T @ torch.ones(n, dtype=tdt, device=dev)
+        step_bf(); barrier()
+        rhs = bvec.clone()
+        h.call(f"rflu_butterfly_vec_{sfx}_dev", n, 1, ctypes.c_void_p(rhs.data_ptr()), n, ctypes.c_void_p(uv.data_ptr()), 1)   # U' b
+        h.call(f"rflu_getrs_{sfx}_dev", n, 1, ctypes.c_void_p(A.data_ptr()), n, ctypes.c_void_p(0), ctypes.c_void_p(rhs.data_ptr()), n)
+        h.call(f"rflu_butterfly_vec_{sfx}_dev", n, 1, ctypes.c_void_p(rhs.data_ptr()), n, ctypes.c_void_p(uv.data_ptr()), 0)   # V y
+        barrier()
+        r = A0.T.to(torch.float64) @ rhs.to(torch.float64) - bvec.to(torch.float64)
+        berr = float((torch.linalg.norm(r) / (torch.linalg.norm(A0.to(torch.float64)) * torch.linalg.norm(rhs.to(torch.float64)))).item())
+        del A0
+        variants = {
+            "nopivot": {"ms": round(1e3 * t_np, 3), "gflops": round(flops / t_np / 1e9, 1),
+                        "frac_of_mfma_peak": round(flops / t_np / 1e12 / PEAK_TFLOPS[sfx], 4),
+                        "note": "lu!(A, Val(false)) on the same uniform input (step = refill + lu!); residual not meaningful without pivoting"},
+            "butterfly": {"ms": round(1e3 * t_bf, 3), "gflops": round(flops / t_bf / 1e9, 1),
+                          "frac_of_mfma_peak": round(flops / t_bf / 1e12 / PEAK_TFLOPS[sfx], 4),
+                          "butterfly_mul_ms": round(bf_ms, 4),
+                          "butterfly_mul_gbs": round(2.0 * esz * n * n / (bf_ms * 1e-3) / 1e9, 1),
+                          "butterfly_mul_frac_of_hbm": round(2.0 * esz * n * n / (bf_ms * 1e-3) / 8e12, 4),
+                          "solve_backward_error": berr,
+                          "note": "step = refill + A <- U'AV (one pass, 2*sizeof(T)*n^2 algorithmic bytes) + lu!(A, Val(false)); "
+                                  "backward error ||A x - b|| / (||A|| ||x||) of x = V ((U'AV) \\ (U'b)), src/butterflylu.jl:45-55"},
+        }
+
     # ---- checks on the last factorization: residual on device (torch as an independent checker) ----
     check = {}
     if not args.no_check and single and n <= 32768:
@@ -478,6 +543,7 @@ def main():
             "roofline": roof,
             "laswp": laswp,
             "sweep": sweep,
+            "variants": variants,
             "cpu_baseline": cpu,
             "check": check,
             "kernel_ms": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in kern.items()},

@@ -1488,6 +1488,18 @@ int rflu_create(rflu_handle_t* handle, int device)
     }
     h->stream = h->own_stream;
     RFLU_HIP(hipMalloc((void**)&h->info_dev, 2 * sizeof(int64_t)));
+    if (const char* e = getenv("RFLU_DUMMY_QUEUES")) {
+        // measurement hook (scripts/queue_collision.py): k extra streams created AND USED here, before the update / side streams
+        // exist.  How many hardware queues the process has touched changes how the schedules' three queues are served (round 2's
+        // "fourth queue" effect): N=16384 82 ms with k = 0..1, 108-114 ms with k = 2..5 -- although kernels of the three streams
+        // still overlap (probed).  Known sensitivity, see DESIGN.md "queues".
+        for (int i = 0; i < atoi(e); ++i) {
+            hipStream_t d;
+            RFLU_HIP(hipStreamCreateWithFlags(&d, hipStreamNonBlocking));
+            RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 8, d));
+            RFLU_HIP(hipStreamSynchronize(d));
+        }
+    }
     RFLU_HIP(hipMalloc((void**)&h->gates, 8 * sizeof(unsigned long long)));
     RFLU_HIP(hipMemset(h->gates, 0, 8 * sizeof(unsigned long long)));
     for (int i = 0; i < 3; ++i) h->gate_ptr[i] = h->gates + i;

@@ -324,11 +324,19 @@ def main():
         if g["launches"] > 0 and g["ms"] > 0:
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
             traffic = None
-            try:  # HBM bytes per launch from the committed PMC passes of this exact workload (profiles/), if present
+            traffic_note = "traffic: null -- no PMC pass of THIS build and workload under profiles/ (scripts/collect_profiles.sh)"
+            try:  # HBM bytes per launch from the committed PMC passes of this exact workload AND build (profiles/), if present
+                import importlib.util
+
                 with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as f:
                     tj = json.load(f)
-                if tj.get("n") == n and tj.get("dtype") == sfx:
+                bspec = importlib.util.spec_from_file_location("_rflu_build", os.path.join(ROOT, "recursivefactorization.jl_amd", "build.py"))
+                bmod = importlib.util.module_from_spec(bspec)
+                bspec.loader.exec_module(bmod)
+                if tj.get("n") == n and tj.get("dtype") == sfx and tj.get("sources_sha1") == bmod.sources_digest():
                     traffic = tj["hbm_bytes_per_launch"]
+                    traffic_note = ("traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes of this "
+                                    "build: " + tj.get("source", "profiles/"))
             except (OSError, ValueError, KeyError):
                 pass
             roof = {"bound": "mfma", "kernel": "gemm_sub_kernel (schur_complement!, C -= A*B)", "achieved": round(ach, 3),
@@ -337,8 +345,7 @@ def main():
                     "flops_per_launch": g["work"] / g["launches"],
                     "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
                     "note": ("all gemm_sub_kernel launches of one profiled factorization (single-stream blocked schedule, HIP "
-                             "events on the launch stream); traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 per launch from "
-                             "profiles/*pmc*") if single else
+                             "events on the launch stream); " + traffic_note) if single else
                             ("rank 0's gemm_sub_kernel launches of one profiled single-stream factorization (per-GPU figure)"
                              if job is not None else
                              "per-GPU kernel: gemm_sub_kernel launches of one profiled single-GPU factorization of the 1-GPU "

@@ -30,6 +30,11 @@ def _digest(paths):
     return h.hexdigest()
 
 
+def sources_digest() -> str:
+    """One hash over every kernel / driver source and header: identifies the build a measurement belongs to."""
+    return _digest([os.path.join(CSRC, f) for f in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS])
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the default bench workload: kernel-trace stats (two runs: the default two-stream schedule) and three
 # separate PMC passes (counters never combined with hip/hsa/sys tracing).  Output: gpurun_out/prof_<tag>/...
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 SIZE=${2:-16384}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 CMD="python bench.py --size $SIZE --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-extras"
@@ -19,6 +19,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -- $CMD1 > /d
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -- $CMD1 > /dev/null 2>$OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES -f csv -d $OUT/pmc_mfma -- $CMD1 > /dev/null 2>$OUT/pmc_mfma.err
 python scripts/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") $(find $OUT/pmc_mfma -name "*counter_collection.csv") > $OUT/pmc.txt
+python scripts/rocpd_blocks.py $DB 1 > $OUT/blocks.txt 2>/dev/null || true
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma   # keep the summaries only (gpurun_out is size-limited)
 cat $OUT/kernel_stats.txt | head -30
 cat $OUT/pmc.txt | grep -E "gemm|==" 

@@ -3,8 +3,10 @@ import sqlite3, collections, re, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = cur.execute("select name, start, end, queue_id, grid_x, workgroup_x from kernels order by start").fetchall()
-tr = [i for i, r in enumerate(rows) if 'transpose' in r[0]]
-a, b = tr[2 * which], tr[2 * which + 1]
+fills = [i for i, r in enumerate(rows) if 'fill_uniform' in r[0]]   # bench.py refills the input before every lu!
+a = fills[which] + 1
+b = fills[which + 1] - 1 if which + 1 < len(fills) else len(rows) - 1
+while 'transpose' not in rows[b][0]: b -= 1
 seg = rows[a:b + 1]
 t0, t1 = seg[0][1], seg[-1][2]
 print("factorization wall: %.2f ms" % ((t1 - t0) / 1e6))

@@ -146,6 +146,25 @@ def test_leafwise_schedule_matches_default(n, bs, monkeypatch):
     assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
 
 
+@pytest.mark.parametrize("env", [{"RFLU_DEEP": "1"}, {"RFLU_DEEP": "1", "RFLU_DEEP_KMAX": "4", "RFLU_DEEP_Q": "2", "RFLU_LEAFWISE_ROWS": "2048"},
+                                 {"RFLU_LEAF_NEXT": "1"}, {"RFLU_DEEP": "1", "RFLU_LEAF_NEXT": "1"}])
+@pytest.mark.parametrize("n,bs", [(4096, 256), (6144, 512), (5000, 256)])
+def test_opt_in_schedules_match_default(n, bs, env, monkeypatch):
+    """The round-3 opt-in variants -- the deep-lookahead schedule (factor_deep: sweeps with per-column state, window stream, K
+    aggregation, also with tall panels factored by the recursion: RFLU_LEAFWISE_ROWS) and the one-launch work between two leaves
+    (leaf_next_kernel) -- apply the same eliminations in the same order as the default schedules: identical pivots, factors equal
+    to rounding, residual below the 1e-12 bar."""
+    A, F = _factor(n, np.float64, True, bs)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _, G = _factor(n, np.float64, True, bs)
+    assert F.info == 0 and G.info == 0
+    assert torch.equal(F.ipiv, G.ipiv)
+    scale = float(F.factors.abs().max())
+    assert float((F.factors - G.factors).abs().max()) <= 1e-10 * scale
+    assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
+
+
 @pytest.mark.parametrize("m,n,bs,dtype,pivot", [
     (3000, 2048, 128, np.float64, True),     # tall: panels of 3000 .. 952 rows
     (2048, 3000, 256, np.float64, True),     # fat: the windows of the last block column reach into the tail (src/lu.jl:148-154)

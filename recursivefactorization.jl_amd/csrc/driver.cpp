@@ -703,10 +703,6 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     bool swap_su = b_begin == 0 && m <= 8192;
     if (const char* e = getenv("RFLU_SWAP_SU")) swap_su = atoi(e) != 0;
     const bool fold = !(getenv("RFLU_GATE_FOLD") && atoi(getenv("RFLU_GATE_FOLD")) == 0) && !getenv("RFLU_GATE_TRACE");
-    // RFLU_LEAF_NEXT=1: the chain's three launches between two leaves as one (laswp.hip: leaf_next_kernel).  Opt-in: measured
-    // N=4096 12.03 -> 11.96 ms, N=8192 26.74 -> 26.58, N=16384 82.56 -> 82.79, Float32 N=16384 62.1 -> 70.3 (leaf-wise from
-    // 16384 rows: 254 waiting workgroups per leaf next to the bulk GEMM) -- the in-kernel hand-overs cost what the launches did.
-    const bool leaf_next_on = [] { const char* e = getenv("RFLU_LEAF_NEXT"); return e != nullptr && atoi(e) != 0; }();
     int64_t confine_rows = (int64_t)1 << 40;
     if (const char* e = getenv("RFLU_CONFINE_ROWS")) confine_rows = atoll(e);
     auto reserve_for = [&](int64_t rows) {
@@ -787,19 +783,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);
             const unsigned long long* wflag = nullptr;   // leaf g-1 reached LA through the side stream: in its own block's part, or the next block's
             if (la1 > la0 && g > gfirst) wflag = h->gate_ptr[la0 < std::min(((c0 - NB) / W + 1) * W, n) ? 1 : 2];
-            bool fused_next = false;
-            if (f.pivot && fold && leaf_next_on && w == NB && la1 - la0 == NB && reinterpret_cast<uintptr_t>(R) % 16 == 0) {
-                // interchanges + inverse + solve + K = 64 update of the next leaf's columns in ONE launch (laswp.hip: leaf_next_kernel),
-                // with both gates riding on it
-                LaswpGate gt;
-                gt.wait_flag = wflag;
-                gt.wait_val = wflag ? val(g - 1) : 0;
-                gt.signal_flag = h->gate_ptr[0];
-                gt.signal_val = val(g);
-                gt.info = h->info_dev;
-                RFLU_TRY(launch_leaf_next<T>(h, R, ld, m, c0, la0, 1, f.linv_at(c0), reinterpret_cast<unsigned*>(h->gates + 6), gt));
-                fused_next = true;
-            } else if (f.pivot && fold) {   // both gates ride on the interchange launch: two launches less per leaf on this stream
+            if (f.pivot && fold) {   // both gates ride on the interchange launch: two launches less per leaf on this stream
                 LaswpGate gt;
                 gt.wait_flag = wflag;
                 gt.wait_val = wflag ? val(g - 1) : 0;
@@ -814,7 +798,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
 
                 RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g), stamp(0, g)));
             }
-            if (!fused_next) RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
+            RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
             // ---- side stream: leaf g on the rest of this block column and on the next one ----
             h->stream = S;
             int rc = launch_gate_wait(h, h->gate_ptr[0], val(g));
@@ -920,10 +904,6 @@ static int factor_deep(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U_bef
     bool swap_su = b_begin == 0 && m <= 8192;   // see factor_leafwise
     if (const char* e = getenv("RFLU_SWAP_SU")) swap_su = atoi(e) != 0;
     const bool fold = !(getenv("RFLU_GATE_FOLD") && atoi(getenv("RFLU_GATE_FOLD")) == 0) && !getenv("RFLU_GATE_TRACE");
-    // RFLU_LEAF_NEXT=1: the chain's three launches between two leaves as one (laswp.hip: leaf_next_kernel).  Opt-in: measured
-    // N=4096 12.03 -> 11.96 ms, N=8192 26.74 -> 26.58, N=16384 82.56 -> 82.79, Float32 N=16384 62.1 -> 70.3 (leaf-wise from
-    // 16384 rows: 254 waiting workgroups per leaf next to the bulk GEMM) -- the in-kernel hand-overs cost what the launches did.
-    const bool leaf_next_on = [] { const char* e = getenv("RFLU_LEAF_NEXT"); return e != nullptr && atoi(e) != 0; }();
     int64_t dwin = 3;
     if (const char* e = getenv("RFLU_DEEP_WIN")) dwin = std::max<int64_t>(1, atoll(e));
     double scale_rec = 1.3, scale_leaf = 1.3;    // share of a block column's time a sweep may fill: the side stream's updates share
@@ -1142,19 +1122,7 @@ static int factor_deep(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U_bef
                 const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);
                 const unsigned long long* wflag = nullptr;   // leaf g-1 reached LA through the side stream: its own block's part, or the next block's
                 if (la1 > la0 && g > gfirst) wflag = h->gate_ptr[la0 < std::min(((c0 - NB) / W + 1) * W, n) ? 1 : 2];
-                bool fused_next = false;
-                if (f.pivot && fold && leaf_next_on && w == NB && la1 - la0 == NB && reinterpret_cast<uintptr_t>(R) % 16 == 0) {
-                    // interchanges + inverse + solve + K = 64 update of the next leaf's columns in ONE launch (laswp.hip: leaf_next_kernel),
-                    // with both gates riding on it
-                    LaswpGate gt;
-                    gt.wait_flag = wflag;
-                    gt.wait_val = wflag ? val(g - 1) : 0;
-                    gt.signal_flag = h->gate_ptr[0];
-                    gt.signal_val = val(g);
-                    gt.info = h->info_dev;
-                    RFLU_TRY(launch_leaf_next<T>(h, R, ld, m, c0, la0, 1, f.linv_at(c0), reinterpret_cast<unsigned*>(h->gates + 6), gt));
-                    fused_next = true;
-                } else if (f.pivot && fold) {   // both gates ride on the interchange launch: two launches less per leaf on this stream
+                if (f.pivot && fold) {
                     LaswpGate gt;
                     gt.wait_flag = wflag;
                     gt.wait_val = wflag ? val(g - 1) : 0;
@@ -1168,7 +1136,7 @@ static int factor_deep(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U_bef
                     if (f.pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0)));
                     RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g)));
                 }
-                if (!fused_next) RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
+                RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
                 // ---- side stream: leaf g on the rest of this block column and on the next one ----
                 h->stream = S;
                 int rc = launch_gate_wait(h, h->gate_ptr[0], val(g));
@@ -1251,7 +1219,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), h->stream));
     // the wrapping "last workgroup" counters of the folded gates: a factorization that timed out or was aborted may have left
     // them mid-count, and a stale count would publish the next factorization's gate early or never
-    RFLU_HIP(hipMemsetAsync(h->gates + 4, 0, 4 * sizeof(unsigned long long), h->stream));   // [4],[5]: gate counters; [6],[7]: leaf_next_kernel's
+    RFLU_HIP(hipMemsetAsync(h->gates + 4, 0, 2 * sizeof(unsigned long long), h->stream));
     if (!pivot && ipiv) RFLU_TRY(launch_iota_ipiv(h, ipiv, 0, mn));  // src/lu.jl:111-113
 
     Fact<T> f{h, R, ld, m, n, ipiv, pivot};

@@ -8,9 +8,6 @@
 // per column of HBM traffic -- no cache-line amplification.
 // Roofline: HBM (8 TB/s spec, ~6.3 TB/s achievable); algorithmic bytes per launch = 4*sizeof(T)*ncols*pivots.
 #include <stdint.h>
-
-#include <algorithm>
-
 #include "rflu_internal.hpp"
 #include "trsm_row.hpp"
 
@@ -25,14 +22,7 @@ namespace rflu {
 // one element per lane for column ranges that are not 16-byte aligned.
 constexpr int LW_WAVES = 4;                   // independent waves per workgroup
 
-// agent-scope relaxed atomic accesses: write-through stores / cache-bypassing loads (sc1), visible to the other workgroups of a
-// running kernel without any fence (the data-tagged records of the panel kernels rely on the same property)
-template <typename T>
-__device__ __forceinline__ void store_coherent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T>
-__device__ __forceinline__ T load_coherent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <typename T, int VW, int LW_LPR, bool SC1 = false>
+template <typename T, int VW, int LW_LPR>
 __device__ __forceinline__ void laswp_strip(T* __restrict__ R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1,
                                             int64_t ncolsB, int64_t c2, int64_t ncolsC, const int* __restrict__ pm_cnt,
                                             const int* __restrict__ pm_dst, const int* __restrict__ pm_src, int chunk0,
@@ -84,14 +74,7 @@ __device__ __forceinline__ void laswp_strip(T* __restrict__ R, int64_t ld, int64
         for (int i = 0; i < LW_NI; ++i) {
             const int e = i * LW_RS + rsub;
             if (i * LW_RS < cur) {
-                if (e < cur && active) {
-                    if constexpr (SC1) {
-#pragma unroll
-                        for (int q = 0; q < VW; ++q) store_coherent(R + (int64_t)dst[i] * ld + col + q, (T)v[i][q]);
-                    } else {
-                        *reinterpret_cast<vec_t*>(R + (int64_t)dst[i] * ld + col) = v[i];
-                    }
-                }
+                if (e < cur && active) *reinterpret_cast<vec_t*>(R + (int64_t)dst[i] * ld + col) = v[i];
             }
         }
     }
@@ -146,207 +129,6 @@ __global__ void __launch_bounds__(64 * LW_WAVES) laswp_kernel(T* __restrict__ R,
         }
     }
 }
-
-// ---- the chain's work between two leaves, in ONE launch (leaf-wise schedule) ----------------------------------------------------
-// After leaf g (columns [c0, c0+64), rows c0..) the next leaf's 64 columns LA = [la0, la0+64) need, in this order: the leaf's
-// interchanges, the block-row solve U12 = inv(L11) A12 and the rank-64 update A22 -= L21 U12 (src/lu.jl:233-240 for these columns).
-// Round 2 spent three dependent launches on that (interchanges + inverse of L11, solve, update: ~65 us with their gaps, 27 % of
-// the chain in the panel-bound part).  Here the steps are ROLES of one launch, ordered by two device-side counters:
-//   workgroup 0   interchanges on LA (4 waves x 16 columns, laswp_strip with write-through stores)              -> swapped = 1
-//   workgroup 1   inverse of the leaf's 64 x 64 diagonal block (to global memory for every later solve, and kept in LDS);
-//                 waits swapped; U12 = inv(L11) * A12 (MFMA), written through                                    -> solved = 1
-//   workgroup 2+t waits solved; rows c0+64+64t.. of LA -= L21 * U12 (one 64 x 64 MFMA tile, L21 requested before the wait)
-// Everything one role hands to another travels as write-through stores and cache-bypassing loads (store_coherent /
-// load_coherent), ordered by the counter alone -- a release fence inside the chain means an L2 write-back next to the bulk
-// GEMM's dirty tiles (measured: the fenced version of this kernel was SLOWER than the three launches).  Workgroups are dispatched
-// in index order, so a waiter never holds a slot its producer needs.  The last workgroup to finish clears the counters and
-// publishes the schedule's stream gate (LaswpGate), like the interchange launch it replaces.
-template <typename T>
-struct MfmaL;
-template <>
-struct MfmaL<double> {
-    typedef double acc_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
-};
-template <>
-struct MfmaL<float> {
-    typedef float acc_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
-};
-
-template <typename T>
-struct LeafNextArgs {
-    T* R;
-    int64_t ld;
-    int m, c0, la0;
-    const int* pm_cnt;
-    const int* pm_dst;
-    const int* pm_src;
-    T* linv_out;
-    unsigned* ctr;   // [0] swapped, [1] solved, [2] finished workgroups (all zero between launches)
-    int pivot;
-    LaswpGate gate;
-};
-
-// one lane polls (cache-bypassing load, no invalidation), the workgroup follows
-__device__ __forceinline__ void leaf_next_wait(const unsigned* flag, int64_t* info)
-{
-    if (threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 200000000LL) {
-                if (info) __hip_atomic_fetch_or((unsigned long long*)(info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) leaf_next_kernel(LeafNextArgs<T> g)
-{
-    typedef typename MfmaL<T>::acc_t acc_t;
-    constexpr int VW = 16 / (int)sizeof(T);
-    typedef T vec_t __attribute__((ext_vector_type(VW)));
-    constexpr int SB = NB + 4;   // B image: 64 columns + one gap element per 16-column block (bank spread, as gemm_skinny_kernel)
-    extern __shared__ __attribute__((aligned(16))) unsigned char ln_smem[];
-    T* sm = reinterpret_cast<T*>(ln_smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (g.gate.wait_flag) {   // folded stream gate: hold until the side stream has applied the previous leaf to these columns
-        if (tid == 0) {
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(g.gate.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < g.gate.wait_val) {
-                __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > 200000000LL) {
-                    __hip_atomic_fetch_or((unsigned long long*)(g.gate.info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    T* const LA = g.R + g.la0;   // column block LA as a matrix with leading dimension ld
-    const int role = (int)blockIdx.x;
-    if (role == 0) {
-        if (g.pivot) laswp_strip<T, VW, 8, true>(g.R, g.ld, g.la0, NB, 0, 0, 0, 0, g.pm_cnt, g.pm_dst, g.pm_src, g.c0 / NB, g.c0 / NB + 1, wave);
-        __syncthreads();   // drains the memory counter: every write-through store of the workgroup has been acknowledged
-        if (tid == 0) __hip_atomic_store(g.ctr + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (role == 1) {
-        T* sX = sm + NB * NB;
-        diag_inv_block4<T>(NB, g.R + (int64_t)g.c0 * g.ld + g.c0, g.ld, g.linv_out, sm, sX, tid);   // inverse also stays in sX
-        leaf_next_wait(g.ctr + 0, g.gate.info);
-        // U12 = inv(L11) * A12 in place (trsm_inv64_kernel's tile): wave w produces rows 16w .. 16w+15
-        const int fi = lane & 15, fk = lane >> 4;
-        T* B = LA + (int64_t)g.c0 * g.ld;
-        T b[16][4];
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b[kk][t] = load_coherent(B + (int64_t)(kk * 4 + fk) * g.ld + t * 16 + fi);
-        T ai[16];
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) ai[kk] = sX[(wave * 16 + fi) * NB + fk + kk * 4];
-        __syncthreads();   // every wave has read all of A12 before any row is overwritten
-        acc_t x[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) x[t] = acc_t{T(0), T(0), T(0), T(0)};
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] = MfmaL<T>::run(ai[kk], b[kk][t], x[t]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) store_coherent(B + (int64_t)(wave * 16 + MfmaL<T>::crow(lane, r)) * g.ld + t * 16 + fi, (T)x[t][r]);
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(g.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        // rows m0 .. m0+63 of LA -= L21 * U12 (gemm_skinny_kernel's tile, K = 64): the A operands do not depend on the other roles
-        const int m0 = g.c0 + NB + (role - 2) * NB;
-        const int li = lane & 15, kk = lane >> 4;
-        const int arow = m0 + wave * 16 + li;
-        const bool arow_ok = arow < g.m;
-        const T* Ap = g.R + (int64_t)(arow_ok ? arow : 0) * g.ld + g.c0 + kk * 16;
-        T ra[16];
-#pragma unroll
-        for (int v = 0; v < 16 / VW; ++v) {
-            const vec_t x = *reinterpret_cast<const vec_t*>(Ap + v * VW);
-#pragma unroll
-            for (int e = 0; e < VW; ++e) ra[v * VW + e] = arow_ok ? x[e] : T(0);
-        }
-        leaf_next_wait(g.ctr + 1, g.gate.info);
-        const int brow = tid >> 2, bcol = (tid & 3) * 16;
-        T rb[16];
-        {
-            const T* Bp = LA + (int64_t)(g.c0 + brow) * g.ld + bcol;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) rb[e] = load_coherent(Bp + e);
-        }
-        T cin[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wave * 16 + MfmaL<T>::crow(lane, r);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cin[j][r] = (row < g.m) ? load_coherent(LA + (int64_t)row * g.ld + j * 16 + li) : T(0);
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sm[brow * SB + bcol + (bcol >> 4) + e] = rb[e];
-        __syncthreads();
-        acc_t acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = acc_t{T(0), T(0), T(0), T(0)};
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            const T* brow_p = &sm[(kk * 16 + st) * SB + li];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = MfmaL<T>::run(ra[st], brow_p[j * 17], acc[j]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wave * 16 + MfmaL<T>::crow(lane, r);
-            if (row < g.m) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) LA[(int64_t)row * g.ld + j * 16 + li] = cin[j][r] - acc[j][r];
-            }
-        }
-    }
-    // the last workgroup to get here clears the counters and publishes the stream gate
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        if (atomicInc(g.ctr + 2, gridDim.x - 1) == gridDim.x - 1) {
-            __hip_atomic_store(g.ctr + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g.ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g.gate.signal_flag) __hip_atomic_store(g.gate.signal_flag, g.gate.signal_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// Leaf (c0, 64 columns, pivot chunk c0/NB) applied to the 64 columns [la0, la0+64): interchanges, inverse of the diagonal block
-// into linv_out, block-row solve, rank-64 update of the rows below -- one launch.  ctr: three zeroed 32-bit words.
-template <typename T>
-int launch_leaf_next(Handle* h, T* R, int64_t ld, int64_t m, int64_t c0, int64_t la0, int pivot, T* linv_out, unsigned* ctr,
-                     LaswpGate gate)
-{
-    LeafNextArgs<T> g;
-    g.R = R; g.ld = ld; g.m = (int)m; g.c0 = (int)c0; g.la0 = (int)la0;
-    g.pm_cnt = h->pm_cnt; g.pm_dst = h->pm_dst; g.pm_src = h->pm_src;
-    g.linv_out = linv_out; g.ctr = ctr; g.pivot = pivot; g.gate = gate;
-    const int64_t below = m - c0 - NB;
-    const int64_t slabs = below > 0 ? (below + NB - 1) / NB : 0;
-    ProfScope ps(h, RFLU_K_GEMM_SMALL, 2.0 * (double)std::max<int64_t>(below, 0) * NB * NB + (double)NB * NB * NB,
-                 sizeof(T) * (3.0 * (double)std::max<int64_t>(below, 0) * NB + 4.0 * NB * NB));
-    const size_t lds = 2 * (size_t)NB * NB * sizeof(T);
-    hipLaunchKernelGGL(leaf_next_kernel<T>, dim3((unsigned)(2 + slabs)), dim3(256), lds, h->stream, g);
-    RFLU_HIP(hipGetLastError());
-    return RFLU_OK;
-}
-template int launch_leaf_next<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int, double*, unsigned*, LaswpGate);
-template int launch_leaf_next<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int, float*, unsigned*, LaswpGate);
 
 // Apply chunks [chunk0, chunk1) to the column ranges [c0, c0+ncolsA) and [c1, c1+ncolsB), and chunks [chunk0+1, chunk1) to
 // [c2, c2+ncolsC); optionally invert inv_cnt consecutive inv_nb x inv_nb unit lower diagonal blocks starting at inv_L

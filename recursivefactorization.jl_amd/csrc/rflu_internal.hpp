@@ -207,10 +207,6 @@ template <typename T>
 int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t chunk0,
                   int64_t chunk1, int64_t inv_nb = 0, const T* inv_L = nullptr, T* inv_out = nullptr,
                   LaswpGate gate = LaswpGate{});
-// the chain's work between two leaves of the leaf-wise schedule in one launch (laswp.hip: leaf_next_kernel)
-template <typename T>
-int launch_leaf_next(Handle* h, T* R, int64_t ld, int64_t m, int64_t c0, int64_t la0, int pivot, T* linv_out, unsigned* ctr,
-                     LaswpGate gate = LaswpGate{});
 // fold the interchanges ipiv[k0..k1) (k0 a multiple of NB) into per-chunk row-move lists
 int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, int64_t m);
 size_t panel_scratch_bytes();

@@ -147,13 +147,12 @@ def test_leafwise_schedule_matches_default(n, bs, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"RFLU_DEEP": "1"}, {"RFLU_DEEP": "1", "RFLU_DEEP_KMAX": "4", "RFLU_DEEP_Q": "2", "RFLU_LEAFWISE_ROWS": "2048"},
-                                 {"RFLU_LEAF_NEXT": "1"}, {"RFLU_DEEP": "1", "RFLU_LEAF_NEXT": "1"}])
+                                 {"RFLU_DEEP": "1", "RFLU_DEEP_WIN": "1", "RFLU_DEEP_SCALE": "0.8"}])
 @pytest.mark.parametrize("n,bs", [(4096, 256), (6144, 512), (5000, 256)])
-def test_opt_in_schedules_match_default(n, bs, env, monkeypatch):
-    """The round-3 opt-in variants -- the deep-lookahead schedule (factor_deep: sweeps with per-column state, window stream, K
-    aggregation, also with tall panels factored by the recursion: RFLU_LEAFWISE_ROWS) and the one-launch work between two leaves
-    (leaf_next_kernel) -- apply the same eliminations in the same order as the default schedules: identical pivots, factors equal
-    to rounding, residual below the 1e-12 bar."""
+def test_deep_schedule_matches_default(n, bs, env, monkeypatch):
+    """The round-3 opt-in deep-lookahead schedule (factor_deep: sweeps with per-column state, window stream, K aggregation, also with
+    tall panels factored by the recursion: RFLU_LEAFWISE_ROWS) applies the same eliminations in the same order as the default
+    schedules: identical pivots, factors equal to rounding, residual below the 1e-12 bar."""
     A, F = _factor(n, np.float64, True, bs)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -41,6 +41,11 @@ struct Mfma<double> {
     static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
+    // c - a*b in one instruction: for the Float64 MFMAs the BLGP field is a set of NEGATE bits (bit 0: A) -> "neg:[1,0,0]"
+    static constexpr bool HAS_NEG = true;
+    static __device__ __forceinline__ acc_t run_neg(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+    }
     // f64 C/D fragment: col = lane & 15, row = (lane >> 4) + 4*r   (cdna_hip_programming.md section 3)
     static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
 };
@@ -51,6 +56,8 @@ struct Mfma<float> {
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
+    static constexpr bool HAS_NEG = false;   // BLGP is a lane-group broadcast pattern for the Float32 MFMAs (no negate bits)
+    static __device__ __forceinline__ acc_t run_neg(float a, float b, acc_t c) { return run(-a, b, c); }   // never instantiated in a hot loop
     // f32 C/D fragment: col = lane & 15, row = 4*(lane >> 4) + r
     static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
 };
@@ -59,7 +66,14 @@ constexpr int G_BM = 128, G_BN = 128, G_BK = 16;
 constexpr int G_SA = G_BK + 1;
 constexpr int G_SB = G_BN + 16;
 constexpr int G_STAGE = G_BM * G_SA + G_BK * G_SB;  // elements per LDS stage
-constexpr int G_GROUP_M = 8;                        // tile rows walked together (L2 reuse of the B panel)
+#ifndef RFLU_GEMM_GROUP_M
+#define RFLU_GEMM_GROUP_M 8
+#endif
+constexpr int G_GROUP_M = RFLU_GEMM_GROUP_M;        // tile rows walked together (L2 reuse of the B panel)
+#ifndef RFLU_GEMM_SSTORE_AT
+#define RFLU_GEMM_SSTORE_AT 4
+#endif
+constexpr int G_SSTORE_AT = RFLU_GEMM_SSTORE_AT;    // before which 4-deep step of a slab the next slab is written to LDS (4 = after the last)
 
 template <typename T>
 struct GemmArgs {
@@ -90,6 +104,12 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
     typedef typename Mfma<T>::acc_t acc_t;
     constexpr int VW = 16 / (int)sizeof(T);  // elements per 16-byte vector
     typedef T vec_t __attribute__((ext_vector_type(VW)));
+    // C_FIRST computes c - sum a*b in the accumulators.  Round 2 negated every A element on its way into LDS (8 VALU ops per thread
+    // and slab, between the wait for the global loads and the LDS writes of the slab transition).  Float64: the MFMA negates A itself
+    // (NEGMOD; sustained 15872^2 x 512: 61.4 -> 64.4 TFLOP/s).  Float32 has no such modifier: the accumulators hold -(c - sum a*b)
+    // instead, negated once on the way in and once on the way out (NEGACC; negation is exact, so the results are bit-identical).
+    constexpr bool NEGMOD = C_FIRST && Mfma<T>::HAS_NEG;
+    constexpr bool NEGACC = C_FIRST && !Mfma<T>::HAS_NEG;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
@@ -157,9 +177,9 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
         T* Bs = As + G_BM * G_SA;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            // C_FIRST: the accumulators start as C itself (loaded straight into them, no dependent VALU before the first
-            // slab), so the products must enter negated; otherwise plain A and the subtraction happens in the epilogue
-            As[a_row * G_SA + a_kb + e] = C_FIRST ? -ra[e] : ra[e];
+            // C_FIRST: the accumulators start as C itself and the products enter negated -- by the MFMA's own negate bit (Float64)
+            // or through negated accumulators (Float32), see NEGMOD / NEGACC; otherwise the subtraction happens in the epilogue
+            As[a_row * G_SA + a_kb + e] = ra[e];
             Bs[b_k * G_SB + b_jb + (b_jb >> 4) + e] = rb[e];
         }
     };
@@ -183,7 +203,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
                 const int col = n0 + wc * 64 + j * 16 + (lane & 15);
                 T cv = T(0);
                 if (C_FIRST && row < g.M && col < g.N) cv = ntc ? __builtin_nontemporal_load(crow_p + j * 16) : crow_p[j * 16];
-                acc[i][j][r] = cv;
+                acc[i][j][r] = NEGACC ? -cv : cv;
             }
         }
     }
@@ -203,6 +223,10 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
         const T* Bs = As + G_BM * G_SA;
 #pragma unroll
         for (int kk = 0; kk < G_BK / 4; ++kk) {
+            // the next slab goes into the OTHER LDS buffer (free since the last barrier) in the middle of this slab's MFMAs: its 16
+            // LDS writes and the wait for its global loads then sit in the shadow of matrix instructions instead of between the
+            // last MFMA and the barrier
+            if (kk == G_SSTORE_AT && kt + 1 < nk) sstore(cur ^ 1);
             T a[4], b[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -212,9 +236,9 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = NEGMOD ? Mfma<T>::run_neg(a[i], b[j], acc[i][j]) : Mfma<T>::run(a[i], b[j], acc[i][j]);
         }
-        if (kt + 1 < nk) sstore(cur ^ 1);
+        if (G_SSTORE_AT >= G_BK / 4 && kt + 1 < nk) sstore(cur ^ 1);
         __syncthreads();
     }
 
@@ -231,8 +255,9 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
                     const int col = n0 + wc * 64 + j * 16 + (lane & 15);
                     if (col < g.N) {
                         if (C_FIRST) {
-                            if (ntc) __builtin_nontemporal_store(acc[i][j][r], crow_p + j * 16);
-                            else crow_p[j * 16] = acc[i][j][r];
+                            const T out = NEGACC ? -acc[i][j][r] : acc[i][j][r];
+                            if (ntc) __builtin_nontemporal_store(out, crow_p + j * 16);
+                            else crow_p[j * 16] = out;
                         } else {
                             crow_p[j * 16] = crow_p[j * 16] - acc[i][j][r];
                         }

@@ -97,7 +97,7 @@ struct GemmArgs {
 };
 
 // C_FIRST: the accumulators start as the C tile (its read overlaps with the first operand slabs, the epilogue only
-// stores): +28 % at K = 256, +8 % at K = 512, but a few % slower from K = 1024 up, where the late read-modify-write wins.
+// stores): +28 % at K = 256, +8 % at K = 512 and, since the negation moved onto the MFMA (round 3), +3..7 % from K = 1024 up too.
 template <typename T, bool C_FIRST>
 __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 {
@@ -428,7 +428,12 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
         g.sig_flag = sig.flag; g.sig_val = sig.val; g.sig_cnt = sig.cnt;
     }
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n;
-    if (K < 1024) hipLaunchKernelGGL((gemm_sub_kernel<T, true>), dim3((unsigned)nwg), dim3(256), lds, h->stream, g);
+    // C_FIRST (accumulators start as the C tile) for every K since round 3: with the products' sign on the MFMA it also wins at
+    // large K (15360^2 x K, TFLOP/s: K=1024 62.7 -> 67.2, 2048 67.4 -> 69.2, 4096 68.0 -> 69.7; N=65536 3219 -> 3124 ms); round 2
+    // switched to the late read-modify-write from K = 1024 on because the per-slab negation cost more there
+    // (RFLU_GEMM_CFIRST_BELOW=1024 restores that)
+    static const int64_t cfirst_below = [] { const char* e = getenv("RFLU_GEMM_CFIRST_BELOW"); return e ? atoll(e) : (int64_t)1 << 40; }();
+    if (K < cfirst_below) hipLaunchKernelGGL((gemm_sub_kernel<T, true>), dim3((unsigned)nwg), dim3(256), lds, h->stream, g);
     else          hipLaunchKernelGGL((gemm_sub_kernel<T, false>), dim3((unsigned)nwg), dim3(256), lds, h->stream, g);
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;

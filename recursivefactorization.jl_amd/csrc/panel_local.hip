@@ -249,7 +249,6 @@ struct XLds {
     unsigned rpos[PANEL_WAVES];
     T w0_lh[2];                // wave 0: l^H of the winner of column c (finishes P_c), by parity of c
     int w0_wl[2];              // wave 0: workgroup of the winner of column c
-    int dead;
     int rows[NB];
 };
 
@@ -298,8 +297,11 @@ __device__ __forceinline__ void x_w0_publish(XLds<T>* sh, u64* scratch, unsigned
 
 // Communication wave before barrier A(c1): finish P_c (c = c1-1) from the winner's row record, poll the G headers of column c1,
 // reduce, complete u_{c1,c1+1}, divide, hand over.
+// Returns true when a peer timed out: the hand-over then carries POS_DEAD as the pivot position, which is how the row waves learn of
+// it (one LDS read per step for everything, instead of a separate flag word read -- and waited for -- ahead of the hand-over).
+constexpr unsigned POS_DEAD = 0x7ffffffeu;
 template <typename T>
-__device__ __forceinline__ void x_w0_exchange(XLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch, int G,
+__device__ __forceinline__ bool x_w0_exchange(XLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch, int G,
                                            int c1, int r0, int g, int lane)
 {
     scratch = uni(scratch);
@@ -351,12 +353,10 @@ __device__ __forceinline__ void x_w0_exchange(XLds<T>* sh, u64* scratch, int64_t
     const T ga = readlane_val(xa, wl), ga1 = readlane_val(xa1, wl), gl = readlane_val(xl, wl);
     T gu = ga1;
     if (c >= 0 && c1 + 1 < NB) gu = ga1 - gl * readlane_val(pc, c1 + 1);   // u_{c1,c1+1}: the entry misses elimination c
-    if (__any(timed_out)) {
-        gp = POS_NONE;
-        if (lane == 0) {
-            __hip_atomic_fetch_or((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh->dead = 1;
-        }
+    const bool dead = __any(timed_out);
+    if (dead) {
+        gp = POS_DEAD;
+        if (lane == 0) __hip_atomic_fetch_or((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const T sc = (ga != T(0)) ? T(1) / ga : T(1);   // once per workgroup
     const T p1 = readlane_val(pc, (c1 + 1) & 63), p2 = readlane_val(pc, (c1 + 2) & 63);   // P_c[c1+1], P_c[c1+2]
@@ -368,13 +368,14 @@ __device__ __forceinline__ void x_w0_exchange(XLds<T>* sh, u64* scratch, int64_t
         h->p2 = p2;
         h->win = gp;
         sh->w0_lh[c1 & 1] = gl;
-        sh->w0_wl[c1 & 1] = (gp != POS_NONE) ? wl : -1;
-        if (g == 0 && gp != POS_NONE) {
+        sh->w0_wl[c1 & 1] = (gp != POS_NONE && !dead) ? wl : -1;
+        if (g == 0 && gp != POS_NONE && !dead) {
             ipiv[r0 + c1] = (int64_t)gp + 1;
             if (ga == T(0) && info[0] == 0) info[0] = (int64_t)r0 + c1 + 1;
         }
     }
     if (c1 >= 1) RFLU_STAMP(scratch, c1 - 1, 7, g, lane);
+    return dead;
 }
 
 // the candidate row staged in LDS (entries c+2..) leaves as ONE coalesced store of the owner's wave
@@ -409,10 +410,11 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
     bool owner = false;
     T l = T(0);
     bool upd = false;
+    unsigned win_c = POS_NONE;
     if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 0, g, tid);
     if constexpr (C >= 0) {
         const XHand<T> h = sh->hand[C & 1];
-        if (sh->dead) { st.dead = true; return; }
+        if (h.win == POS_DEAD) { st.dead = true; return; }
         owner = st.pos == h.cpos && st.pos != POS_NONE;
         if constexpr (C >= 1) {
             if (st.updprev) {   // elimination C-1 on the two entries the next record needs
@@ -433,8 +435,7 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
                 if constexpr (C + 1 < NB) a[C + 1] -= l * h.wu;
             }
         }
-        if (g == 0 && wave == PW - 1 && h.win != POS_NONE)
-            perm_state_step(perm, p.r0, C, __builtin_amdgcn_readfirstlane((int)h.win), lane);
+        win_c = h.win;
     }
     const bool more = C + 1 < p.w;   // workgroup-uniform
     if constexpr (C + 1 < NB) {
@@ -446,6 +447,12 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
             if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 2, g, tid);
             if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 3, g, tid);
         }
+    }
+    // interchange bookkeeping of column C (one wave of workgroup 0): AFTER barrier B, next to the exchange -- before it, that
+    // wave reached the barrier ~40 instructions after everybody else, every step, and every workgroup waits for the slowest one
+    if constexpr (C >= 0) {
+        if (g == 0 && wave == PW - 1 && win_c != POS_NONE)
+            perm_state_step(perm, p.r0, C, __builtin_amdgcn_readfirstlane((int)win_c), lane);
     }
     if constexpr (C >= 0 && C + 2 < NB) {
         if (owner) {   // Rw(C): a[C+2] has elimination C-1, the rest C-2 (the deferred loop below has not run yet)
@@ -510,10 +517,7 @@ __global__ void __launch_bounds__(PW * 64 + 64) panel_pivot_local_kernel(LocalAr
     st.pos = st.act ? (unsigned)row : POS_NONE;
     st.updprev = false;
     st.dead = false;
-    if (tid == 0) {
-        sh->dead = 0;
-        sh->w0_wl[0] = sh->w0_wl[1] = -1;
-    }
+    if (tid == 0) sh->w0_wl[0] = sh->w0_wl[1] = -1;
     T a[NB];
     load_row_direct<T>(p.R, p.ld, row, st.act, p.c0, p.w, a);
     __syncthreads();
@@ -525,9 +529,9 @@ __global__ void __launch_bounds__(PW * 64 + 64) panel_pivot_local_kernel(LocalAr
         for (int c1 = 0; c1 < p.w; ++c1) {
             barrier_lds_only();   // B(c1 - 1): the wave records of column c1 are in LDS
             x_w0_publish<T, AUX, PW>(sh, p.scratch, p.epoch, c1, g, lane);
-            x_w0_exchange<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, c1, p.r0, g, lane);
+            const bool dead = x_w0_exchange<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, c1, p.r0, g, lane);
             barrier_lds_only();   // A(c1)
-            if (sh->dead) break;
+            if (dead) break;
         }
     } else {
         XSteps<T, -1, NB, AUX, PW>::run(p, sh, a, lprev, st, perm, g, tid);

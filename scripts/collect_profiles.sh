@@ -20,6 +20,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -- $CMD1 > /d
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES -f csv -d $OUT/pmc_mfma -- $CMD1 > /dev/null 2>$OUT/pmc_mfma.err
 python scripts/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") $(find $OUT/pmc_mfma -name "*counter_collection.csv") > $OUT/pmc.txt
 python scripts/rocpd_blocks.py $DB 1 > $OUT/blocks.txt 2>/dev/null || true
+python scripts/rocpd_blocks.py $DB 2 > $OUT/blocks2.txt 2>/dev/null || true
+python scripts/rocpd_queues.py $DB 2 > $OUT/queues2.txt 2>/dev/null || true
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma   # keep the summaries only (gpurun_out is size-limited)
 cat $OUT/kernel_stats.txt | head -30
 cat $OUT/pmc.txt | grep -E "gemm|==" 

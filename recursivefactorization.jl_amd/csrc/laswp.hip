@@ -15,8 +15,8 @@ namespace rflu {
 
 // Geometry (round 3).  A row segment is 8 lanes x 16 bytes = one 128-byte line (16 Float64 / 32 Float32 columns); a wave holds 8
 // row slots, so the <= 128 moves of a chunk are 16 independent 16-byte loads per lane, ALL in flight before the first store
-// (16 KB per wave).  Every WAVE owns its column strip for all chunks of the launch: loads and stores of one wave to the same
-// address stay in program order, so there is no workgroup barrier anywhere (round 2: two __syncthreads per chunk, 8-byte
+// (16 KB per wave).  Every WAVE owns its column strip for all chunks of the launch: nothing but that wave touches the
+// strip (its stores are drained between chunks), so there is no workgroup barrier anywhere (round 2: two __syncthreads per chunk, 8-byte
 // accesses, and 64 KB of static LDS in every workgroup -- 2 workgroups per CU -- for the one workgroup that inverts a diagonal
 // block).  The next chunk's move list is requested before the current chunk's rows are stored.  VW = 1 is the same kernel with
 // one element per lane for column ranges that are not 16-byte aligned.
@@ -77,6 +77,10 @@ __device__ __forceinline__ void laswp_strip(T* __restrict__ R, int64_t ld, int64
                 if (e < cur && active) *reinterpret_cast<vec_t*>(R + (int64_t)dst[i] * ld + col) = v[i];
             }
         }
+        // a row written in this chunk may be read in the next one by ANOTHER lane of the wave: have every store acknowledged
+        // first (the memory pipeline keeps one wave's accesses in order anyway -- every parity test passes without this wait --
+        // but the guarantee is per lane; the wait costs 2 % of the wide launches: 3.1 -> 3.03 TB/s)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 

@@ -389,6 +389,28 @@ def main():
                 tw = lw_wide["work"] / (lw_wide["ms"] * 1e-3) / 1e12
                 laswp["wide"] = {"achieved": round(tw * 1e3, 1), "frac": round(tw / 8.0, 4), "launches": lw_wide["launches"],
                                  "total_ms": round(lw_wide["ms"], 3), "share_of_bytes": round(lw_wide["work"] / lw["work"], 3)}
+        # the same kernel with the GPU to itself: one block column's 512 interchanges over all n columns (pivot rows uniform over
+        # the rows below), ten launches, event pairs as above.  The in-schedule figure runs on the CU-masked stream next to the
+        # chain's kernels and on column ranges that shrink with the trailing matrix; this one says what the kernel can do.
+        if laswp is not None and pivot and n >= 1024:
+            npv = min(512, n // 2)
+            ip2 = torch.arange(1, n + 1, dtype=torch.int64, device=dev)
+            ip2[:npv] = torch.randint(npv, n, (npv,), device=dev, generator=torch.Generator(device=dev).manual_seed(7)) + 1
+            call = lambda: h.call(f"rflu_laswp_rm_{sfx}_dev", ctypes.c_void_p(A.data_ptr()), n, n, 0, n,
+                                  ctypes.c_void_p(ip2.data_ptr()), 0, npv)
+            call(); barrier()
+            h.profile_enable(2)
+            for _ in range(10):
+                call()
+            barrier()
+            ka = h.profile()
+            h.profile_enable(False)
+            la = {k: ka["laswp"][k] + ka["laswp_wide"][k] for k in ("ms", "launches", "work")}
+            if la["launches"] > 0 and la["ms"] > 0:
+                ta = la["work"] / (la["ms"] * 1e-3) / 1e12
+                laswp["alone"] = {"achieved": round(ta * 1e3, 1), "frac": round(ta / 8.0, 4), "launches": la["launches"],
+                                  "avg_launch_us": round(la["ms"] * 1e3 / la["launches"], 2),
+                                  "workload": f"{npv} interchanges x {n} columns, nothing else on the GPU"}
         # BASELINE config 2: the block-size sweep 64 / 128 / 256 at this size (two timed factorizations each)
         if pivot and args.blocksize == 0 and n >= 1024:
             sweep = []

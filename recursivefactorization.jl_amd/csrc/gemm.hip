@@ -73,6 +73,14 @@ constexpr int G_GROUP_M = RFLU_GEMM_GROUP_M;        // tile rows walked together
 #ifndef RFLU_GEMM_SSTORE_AT
 #define RFLU_GEMM_SSTORE_AT 4
 #endif
+#ifndef RFLU_GEMM_PRIO
+#define RFLU_GEMM_PRIO 1
+#endif
+#ifndef RFLU_GEMM_DEEP
+#define RFLU_GEMM_DEEP 0
+#endif
+constexpr int G_PRIO = RFLU_GEMM_PRIO;              // wave priority during a slab's MFMA burst (0 = leave it alone)
+constexpr bool G_DEEP = RFLU_GEMM_DEEP != 0;        // operand slabs requested two ahead instead of one
 constexpr int G_SSTORE_AT = RFLU_GEMM_SSTORE_AT;    // before which 4-deep step of a slab the next slab is written to LDS (4 = after the last)
 
 template <typename T>
@@ -211,6 +219,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
     const int nk = (g.K + G_BK - 1) / G_BK;
     if (!early) gload(0);
     sstore(0);
+    if (G_DEEP && nk > 1) gload(G_BK);   // one slab further ahead: the registers are refilled right after each LDS write
     __syncthreads();
 
     const int a_frag = (wr * 64 + (lane & 15)) * G_SA + (lane >> 4);
@@ -218,15 +227,16 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * G_BK);
+        if (!G_DEEP && kt + 1 < nk) gload((kt + 1) * G_BK);
         const T* As = smem + cur * G_STAGE;
         const T* Bs = As + G_BM * G_SA;
+        if (G_PRIO) __builtin_amdgcn_s_setprio(G_PRIO);
 #pragma unroll
         for (int kk = 0; kk < G_BK / 4; ++kk) {
             // the next slab goes into the OTHER LDS buffer (free since the last barrier) in the middle of this slab's MFMAs: its 16
             // LDS writes and the wait for its global loads then sit in the shadow of matrix instructions instead of between the
             // last MFMA and the barrier
-            if (kk == G_SSTORE_AT && kt + 1 < nk) sstore(cur ^ 1);
+            if (kk == G_SSTORE_AT && kt + 1 < nk) { sstore(cur ^ 1); if (G_DEEP && kt + 2 < nk) gload((kt + 2) * G_BK); }
             T a[4], b[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -238,7 +248,8 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = NEGMOD ? Mfma<T>::run_neg(a[i], b[j], acc[i][j]) : Mfma<T>::run(a[i], b[j], acc[i][j]);
         }
-        if (G_SSTORE_AT >= G_BK / 4 && kt + 1 < nk) sstore(cur ^ 1);
+        if (G_PRIO) __builtin_amdgcn_s_setprio(0);
+        if (G_SSTORE_AT >= G_BK / 4 && kt + 1 < nk) { sstore(cur ^ 1); if (G_DEEP && kt + 2 < nk) gload((kt + 2) * G_BK); }
         __syncthreads();
     }
 

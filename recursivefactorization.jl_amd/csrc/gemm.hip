@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "rflu_internal.hpp"
 
@@ -76,11 +77,10 @@ constexpr int G_GROUP_M = RFLU_GEMM_GROUP_M;        // tile rows walked together
 #ifndef RFLU_GEMM_PRIO
 #define RFLU_GEMM_PRIO 1
 #endif
-#ifndef RFLU_GEMM_DEEP
-#define RFLU_GEMM_DEEP 0
-#endif
-constexpr int G_PRIO = RFLU_GEMM_PRIO;              // wave priority during a slab's MFMA burst (0 = leave it alone)
-constexpr bool G_DEEP = RFLU_GEMM_DEEP != 0;        // operand slabs requested two ahead instead of one
+// Wave priority during a slab's MFMA burst, back to 0 for the LDS writes and the barrier: with two workgroups per CU the wave
+// that is inside its burst keeps the matrix pipe while the other one's staging instructions fill the gaps
+// (sustained 15872^2 x 512: 64.3 -> 65.4 TFLOP/s; 1 and 3 measure the same).  0 = leave the priority alone.
+constexpr int G_PRIO = RFLU_GEMM_PRIO;
 constexpr int G_SSTORE_AT = RFLU_GEMM_SSTORE_AT;    // before which 4-deep step of a slab the next slab is written to LDS (4 = after the last)
 
 template <typename T>
@@ -199,27 +199,33 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
     const bool ntc = (g.flags & 2) != 0;
     if (early) gload(0);
     // For a fixed (i,j,r) sixteen lanes cover 16 consecutive columns of one row of C.
+    // An interior tile (full_mn, workgroup-uniform) takes a copy of the loop without the per-element bounds tests: predicated, each
+    // of the 64 loads here and the 64 stores of the epilogue is ~6 scalar/vector instructions around one memory instruction.
     acc_t acc[4][4];
+    auto load_c = [&](auto interior) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wr * 64 + i * 16 + Mfma<T>::crow(lane, r);
-            const T* crow_p = g.C + (int64_t)row * g.ldc + n0 + wc * 64 + (lane & 15);
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * 64 + i * 16 + Mfma<T>::crow(lane, r);
+                const T* crow_p = g.C + (int64_t)row * g.ldc + n0 + wc * 64 + (lane & 15);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wc * 64 + j * 16 + (lane & 15);
-                T cv = T(0);
-                if (C_FIRST && row < g.M && col < g.N) cv = ntc ? __builtin_nontemporal_load(crow_p + j * 16) : crow_p[j * 16];
-                acc[i][j][r] = NEGACC ? -cv : cv;
+                for (int j = 0; j < 4; ++j) {
+                    const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+                    T cv = T(0);
+                    if (C_FIRST && (decltype(interior)::value || (row < g.M && col < g.N)))
+                        cv = ntc ? __builtin_nontemporal_load(crow_p + j * 16) : crow_p[j * 16];
+                    acc[i][j][r] = NEGACC ? -cv : cv;
+                }
             }
         }
-    }
+    };
+    if (full_mn) load_c(std::true_type{});
+    else load_c(std::false_type{});
 
     const int nk = (g.K + G_BK - 1) / G_BK;
     if (!early) gload(0);
     sstore(0);
-    if (G_DEEP && nk > 1) gload(G_BK);   // one slab further ahead: the registers are refilled right after each LDS write
     __syncthreads();
 
     const int a_frag = (wr * 64 + (lane & 15)) * G_SA + (lane >> 4);
@@ -227,7 +233,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (!G_DEEP && kt + 1 < nk) gload((kt + 1) * G_BK);
+        if (kt + 1 < nk) gload((kt + 1) * G_BK);
         const T* As = smem + cur * G_STAGE;
         const T* Bs = As + G_BM * G_SA;
         if (G_PRIO) __builtin_amdgcn_s_setprio(G_PRIO);
@@ -236,7 +242,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
             // the next slab goes into the OTHER LDS buffer (free since the last barrier) in the middle of this slab's MFMAs: its 16
             // LDS writes and the wait for its global loads then sit in the shadow of matrix instructions instead of between the
             // last MFMA and the barrier
-            if (kk == G_SSTORE_AT && kt + 1 < nk) { sstore(cur ^ 1); if (G_DEEP && kt + 2 < nk) gload((kt + 2) * G_BK); }
+            if (kk == G_SSTORE_AT && kt + 1 < nk) sstore(cur ^ 1);
             T a[4], b[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -249,34 +255,38 @@ __global__ void __launch_bounds__(256, 2) gemm_sub_kernel(GemmArgs<T> g)
                 for (int j = 0; j < 4; ++j) acc[i][j] = NEGMOD ? Mfma<T>::run_neg(a[i], b[j], acc[i][j]) : Mfma<T>::run(a[i], b[j], acc[i][j]);
         }
         if (G_PRIO) __builtin_amdgcn_s_setprio(0);
-        if (G_SSTORE_AT >= G_BK / 4 && kt + 1 < nk) { sstore(cur ^ 1); if (G_DEEP && kt + 2 < nk) gload((kt + 2) * G_BK); }
+        if (G_SSTORE_AT >= G_BK / 4 && kt + 1 < nk) sstore(cur ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue: C = C_in - A*B   (C_FIRST: acc already holds it)
+    auto store_c = [&](auto interior) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wr * 64 + i * 16 + Mfma<T>::crow(lane, r);
-            if (row < g.M) {
-                T* crow_p = g.C + (int64_t)row * g.ldc + n0 + wc * 64 + (lane & 15);
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * 64 + i * 16 + Mfma<T>::crow(lane, r);
+                if (decltype(interior)::value || row < g.M) {
+                    T* crow_p = g.C + (int64_t)row * g.ldc + n0 + wc * 64 + (lane & 15);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = n0 + wc * 64 + j * 16 + (lane & 15);
-                    if (col < g.N) {
-                        if (C_FIRST) {
-                            const T out = NEGACC ? -acc[i][j][r] : acc[i][j][r];
-                            if (ntc) __builtin_nontemporal_store(out, crow_p + j * 16);
-                            else crow_p[j * 16] = out;
-                        } else {
-                            crow_p[j * 16] = crow_p[j * 16] - acc[i][j][r];
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+                        if (decltype(interior)::value || col < g.N) {
+                            if (C_FIRST) {
+                                const T out = NEGACC ? -acc[i][j][r] : acc[i][j][r];
+                                if (ntc) __builtin_nontemporal_store(out, crow_p + j * 16);
+                                else crow_p[j * 16] = out;
+                            } else {
+                                crow_p[j * 16] = crow_p[j * 16] - acc[i][j][r];
+                            }
                         }
                     }
                 }
             }
         }
-    }
+    };
+    if (full_mn) store_c(std::true_type{});
+    else store_c(std::false_type{});
     if (in_first && g.sig_flag) {   // workgroup-uniform
         __syncthreads();
         if (tid == 0) {

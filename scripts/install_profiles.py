@@ -1,0 +1,83 @@
+"""Copy the summaries scripts/collect_profiles.sh and the size/microbench runs left under gpurun_out/ into profiles/ with headers
+that say what they are and which build (hash of the kernel sources) they belong to.
+usage: python scripts/install_profiles.py r03c   (reads gpurun_out/prof_<tag>{,_n4096}/ and gpurun_out/r03/)"""
+import importlib.util, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("_rflu_build", os.path.join(ROOT, "recursivefactorization.jl_amd", "build.py"))
+B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)
+tag = sys.argv[1]
+rnd = tag[:3]
+sha = B.sources_digest()[:8]
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+rd = lambda *p: open(os.path.join(G, *p)).read()
+
+def stats_header(n):
+    return (f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}, profiles/gemm_traffic.json) -- rocprofv3 --kernel-trace --stats -- python bench.py --size {n} --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-extras\n"
+            "# (3 timed factorizations incl. warm-up in the shipped schedule + 1 profiled single-stream pass; Float64, one MI355X; scripts/collect_profiles.sh)\n"
+            "# first table: all kernels of the run (scripts/rocpd_summary.py); second: one timed factorization split by HIP queue\n"
+            "# (scripts/rocpd_queues.py): the caller's stream = critical path, the CU-masked update stream, and -- from the first panel of\n"
+            "# <= 8192 rows on -- the side stream of the leaf-wise schedule.  gate_wait_kernel time is waiting, not work; laswp_kernel on the\n"
+            "# caller's stream includes the folded gate wait.\n"
+            "# third: the profiled single-stream pass: bench.py's roofline.avg_launch_ms is the gemm_sub_kernel average of THAT pass.\n")
+
+def pmc_header(n):
+    return (f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}) -- PMC passes, each its own run with --kernel-trace only (scripts/collect_profiles.sh):\n"
+            f"#   rocprofv3 --kernel-trace --pmc <COUNTERS> -f csv -- python bench.py --size {n} --steps 1 --warmup 0 --no-cpu-baseline --no-check --no-extras\n"
+            "# Counter collection serialises kernels across queues, so these runs use the block-column lookahead schedule with event edges only\n"
+            "# (device-side gates cannot make progress when one kernel runs at a time) -- same kernels, same shapes for the bulk GEMM.  Two\n"
+            "# factorizations per run (timed schedule + profiled single-stream pass).  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports\n"
+            "# 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> read bytes = 2*FETCH_SIZE*1024.\n")
+
+for n, d in ((16384, f"prof_{tag}"), (4096, f"prof_{tag}_n4096")):
+    if not os.path.isdir(os.path.join(G, d)):
+        continue
+    open(os.path.join(P, f"{tag}_n{n}_kernel_stats.txt"), "w").write(stats_header(n) + rd(d, "kernel_stats.txt"))
+    open(os.path.join(P, f"{tag}_n{n}_pmc.txt"), "w").write(pmc_header(n) + rd(d, "pmc.txt"))
+    if n == 16384:
+        open(os.path.join(P, f"{tag}_n{n}_blocks.txt"), "w").write(
+            f"# round {int(rnd[1:])}, shipped build -- same rocprofv3 --kernel-trace run as {tag}_n{n}_kernel_stats.txt, one timed factorization\n"
+            "# (scripts/rocpd_blocks.py): when every block column's first leaf starts on the critical-path queue, and how busy each queue is\n"
+            "# per 5 ms window.  Queue 1 = caller's stream (chain), queue 3 = update stream (224 CUs), queue 4 = side stream of the leaf-wise part.\n"
+            + rd(d, "blocks.txt"))
+
+# ---- size table
+rows = []
+for f in sorted(os.listdir(os.path.join(G, "r03"))):
+    if f.startswith("bench_n") and f.endswith(".json"):
+        d = json.loads(rd("r03", f))
+        c = d.get("check") or {}
+        res = c.get("residual_fro", "n/a (n > 32768: checked by tests/test_gpu_configs.py)")
+        rows.append((d["dtype"], not d["config"].get("pivot", True), d["config"]["n"],
+                     f"{d['config']['n']:6d}  {d['dtype']}   {str(d['config'].get('pivot', True)):5s} {d['ms_per_step']:10.3f} {d['value'] / 1e3:9.2f}  {d['frac_of_mfma_peak']:.4f}   {res}"))
+rows.sort()
+dflt = json.loads(rd("r03", "bench_default.json"))
+out = [f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}): python bench.py --size N [--dtype f32] [--nopivot] --steps 5|3 --warmup 1 --no-cpu-baseline --no-extras",
+       "# one MI355X box, one gpurun call (boxes of the pool differ by 3-5 % on the GEMM-bound sizes); the JSON lines are under gpurun_out/r03/ (scratch)",
+       "# n      dtype pivot   ms/step   TFLOP/s  frac of dense MFMA peak (78.6 f64 / 157.3 f32)   ||PA-LU||/||A||"]
+out += [r[3] for r in rows]
+out += ["", "# default bench line of the same call (python bench.py --steps 8 --warmup 2), extra keys:"]
+rf = dflt["roofline"]
+out.append("# roofline: " + json.dumps({k: rf.get(k) for k in ("achieved", "frac", "achieved_in_schedule", "frac_in_schedule", "avg_launch_ms", "traffic")}))
+lw = dflt.get("laswp") or {}
+out.append(f"# laswp.wide: {json.dumps(lw.get('wide'))}  all launches: {lw.get('achieved')} GB/s, {lw.get('total_ms')} ms")
+out.append(f"# laswp.alone: {json.dumps(lw.get('alone'))}")
+out.append("# sweep: " + json.dumps(dflt.get("sweep")))
+out.append("# variants: " + json.dumps(dflt.get("variants")))
+cb = dflt.get("cpu_baseline") or {}
+out.append("# cpu_baseline: " + json.dumps({k: cb.get(k) for k in ("value", "unit", "cores", "kind")}))
+out.append(f"# ms_per_step {dflt['ms_per_step']}  value {dflt['value']}  check {json.dumps(dflt.get('check'))}")
+def block(title, *files, keep=""):
+    out.append("")
+    out.append(title)
+    for f in files:
+        p = os.path.join(G, "r03", f)
+        if os.path.exists(p):
+            out.extend("# " + l.rstrip() for l in open(p) if l.strip() and "amdgpu.ids" not in l and keep in l)
+block("# bulk GEMM alone (scripts/microbench_gemm_sustained.py: 15872^2 x 512 back to back, f64 then f32; scripts/microbench_gemm_k.py: 15360^2 x K):",
+      "gemm_sustained.txt", "gemm_sustained_f32.txt", "gemm_k.txt")
+block("# row interchanges alone (scripts/microbench_laswp.py: 512 interchanges x 16384 columns, C-ABI call = bookkeeping kernel + laswp_kernel):", "laswp_alone.txt")
+block("# host-pointer entry (scripts/microbench_host_entry.py, one caller buffer refilled in place):", "host_entry.txt")
+block("# cooperative leaf alone on the GPU (scripts/panel_bench.py, mode 2 = shipped kernel):", "panel_bench.txt", keep="mode 2")
+open(os.path.join(P, f"{tag}_sizes.txt"), "w").write("\n".join(out) + "\n")
+print("\n".join(out[:16]))

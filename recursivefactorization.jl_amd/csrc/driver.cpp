@@ -391,6 +391,64 @@ static int get_pstream(Handle* h, int reserve, hipStream_t* out)
     return RFLU_OK;
 }
 
+// ---- the schedules' streams on different hardware pipes -------------------------------------------------------------------------
+// Every stream with a CU mask is an HSA queue of its own, and queues are spread round-robin over the 4 pipes of the compute
+// micro-engine in the order the PROCESS created them.  Two busy queues on one pipe cost every kernel of both ~20 us
+// (queue_probe_rate: 5-6 us per back-to-back one-thread kernel on either stream alone or on different pipes, 24-27 us when the two
+// share one; N=4096 12 -> 20 ms, N=16384 82 -> 108 ms when the update or the side stream lands on the critical path's pipe).  Which
+// queue index a new stream gets depends on how many queues the host program created before -- so it is measured, not assumed: each of
+// the library's masked streams is probed against the caller's stream and the ones already accepted, and replaced by a new one with
+// the same mask (the next queue index) until it shares a pipe with none of them; the rejected streams stay parked, idle.
+// Re-checked when the caller's stream changes (rflu_set_stream) or a new masked stream appears.  RFLU_QUEUE_CHECK=0 skips it.
+static int validate_queues(Handle* h)
+{
+    static const bool off = [] { const char* e = getenv("RFLU_QUEUE_CHECK"); return e && atoi(e) == 0; }();
+    if (off) return RFLU_OK;
+    int created = 0;
+    for (int r = 1; r < 8; ++r) created += (h->ustreams[r] != nullptr) + (h->pstreams[r] != nullptr);
+    if (h->queues_ok_stream == h->stream && h->queues_ok_valid && h->queues_ok_count == created) return RFLU_OK;
+    if (!h->qprobe_slots) RFLU_HIP(hipMalloc((void**)&h->qprobe_slots, 8 * sizeof(long long)));
+    const hipStream_t P = h->stream;
+    constexpr int NPROBE = 128;   // the second half is timed (queue_probe_rate)
+    double base = 0;
+    RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));
+    RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));   // the first pass warms the launch path
+    const double limit = std::max(2.0 * base, base + 5.0);   // measured: 5-7.5 us on different pipes, 19-27 on one
+    std::vector<hipStream_t> accepted{P};
+    const bool verbose = getenv("RFLU_QUEUE_TRACE") != nullptr;
+    auto settle = [&](hipStream_t* slot, int r, bool complement) -> int {
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            double worst = 0;
+            for (hipStream_t s : accepted) {
+                double us = 0;
+                RFLU_TRY(queue_probe_rate(s, *slot, NPROBE, h->qprobe_slots, &us));
+                worst = std::max(worst, us);
+            }
+            if (verbose)
+                fprintf(stderr, "[rflu] queue check %s[%d] attempt %d: %.1f us per kernel next to the accepted streams (alone %.1f)\n",
+                        complement ? "pstream" : "ustream", r, attempt, worst, base);
+            if (worst <= limit) break;
+            if (attempt == 7) break;   // keep the last one: never fail a factorization over placement
+            h->parked_streams.push_back(*slot);
+            *slot = nullptr;
+            hipStream_t fresh;
+            if (complement) RFLU_TRY(get_pstream(h, 32 * r, &fresh));
+            else RFLU_TRY(get_ustream(h, 32 * r, &fresh));
+            if (h->mask_failed) return RFLU_OK;
+        }
+        accepted.push_back(*slot);
+        return RFLU_OK;
+    };
+    for (int r = 1; r < 8; ++r)
+        if (h->ustreams[r]) RFLU_TRY(settle(&h->ustreams[r], r, false));
+    for (int r = 1; r < 8; ++r)
+        if (h->pstreams[r]) RFLU_TRY(settle(&h->pstreams[r], r, true));
+    h->queues_ok_stream = P;
+    h->queues_ok_valid = true;
+    h->queues_ok_count = created;
+    return RFLU_OK;
+}
+
 // ---- cost model of the lookahead schedule (microseconds; calibrated on MI355X) ----
 static double model_panel_us(int64_t rows, int64_t W)
 {
@@ -1257,6 +1315,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             RFLU_TRY(get_ustream(h, 32, &probe));
             RFLU_TRY(get_ustream(h, 64, &probe));
             if (h->mask_failed) leafwise = 0;
+            if (!h->mask_failed) RFLU_TRY(validate_queues(h));
         }
         const int64_t Wb = round_up(blocksize, NB);
         const auto t_enq0 = std::chrono::steady_clock::now();
@@ -1351,6 +1410,12 @@ static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int6
         }
         hipStream_t U0, user = h->stream;
         RFLU_TRY(get_ustream(h, 32, &U0));
+        {   // settle which streams the schedules will use BEFORE work goes onto one of them (validate_queues may replace a stream)
+            hipStream_t s64;
+            RFLU_TRY(get_ustream(h, 64, &s64));
+            if (!h->mask_failed) RFLU_TRY(validate_queues(h));
+            RFLU_TRY(get_ustream(h, 32, &U0));
+        }
         RFLU_HIP(hipEventRecord(h->tail_fork_obj, user));            // whatever produced A on the caller's stream
         RFLU_HIP(hipStreamWaitEvent(U0, h->tail_fork_obj, 0));
         RFLU_TRY(launch_transpose<T>(h, m, W0, A, lda, R, ldr));
@@ -1546,6 +1611,9 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->info_pinned) (void)hipHostFree(h->info_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipStream_t ps : h->parked_streams)
+        if (ps) (void)hipStreamDestroy(ps);
+    if (h->qprobe_slots) (void)hipFree(h->qprobe_slots);
     for (hipStream_t us : h->ustreams)
         if (us) (void)hipStreamDestroy(us);
     for (hipStream_t ps : h->pstreams)
@@ -1873,6 +1941,14 @@ static int mgpu_update(Handle* h, int64_t n, T* R, int64_t ld, const T* pb, int6
     return RFLU_OK;
 }
 
+// CUs the next owner of a tall panel keeps away from its share of the update (mgpu_getrf); RFLU_MGPU_BIG_RESERVE overrides
+static int64_t mgpu_big_reserve()
+{
+    int64_t v = 128;
+    if (const char* e = getenv("RFLU_MGPU_BIG_RESERVE")) v = std::min<int64_t>(224, std::max<int64_t>(0, atoll(e) / 32 * 32));
+    return v;
+}
+
 template <typename T>
 static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, int64_t* ipiv_host, int pivot, int64_t block,
                       int64_t run, int64_t* info)
@@ -1917,6 +1993,15 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
         }
         RFLU_TRY(get_ustream(h, 32, &g->U[d]));   // the update stream a device starts on (the mask leaves 32 CUs to the panel)
         g->P[d] = h->own_stream;
+        if (!g->fake && !h->mask_failed) {
+            // the streams this device will run side by side -- panel stream, 32-CU mask and (next owner of a tall panel) the big
+            // mask -- on different hardware pipes (validate_queues); logical devices on one GPU share its 4 pipes anyway
+            hipStream_t big;
+            if (D > 1 && mgpu_big_reserve() > 32) RFLU_TRY(get_ustream(h, (int)mgpu_big_reserve(), &big));
+            h->stream = g->P[d];
+            RFLU_TRY(validate_queues(h));
+            RFLU_TRY(get_ustream(h, 32, &g->U[d]));   // may have been replaced
+        }
         h->last_path = RFLU_PATH_HIP_LOOKAHEAD;
         // start state on both streams of the device
         h->stream = g->U[d];
@@ -2011,8 +2096,7 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
     // reservation (ONE extra stream per device: panel stream, 32-CU mask, big mask -- the fourth queue costs 25 %, DESIGN.md
     // "queues").  Only a panel that needs even more is factored BEFORE the owner's bulk update (round 2 did that from 16384
     // rows on: at N=65536 over 8 GPUs 96 of 128 block columns, ~0.3 s of un-overlapped panels).
-    int64_t big_reserve = 128;
-    if (const char* e = getenv("RFLU_MGPU_BIG_RESERVE")) big_reserve = std::min<int64_t>(224, std::max<int64_t>(0, atoll(e) / 32 * 32));
+    const int64_t big_reserve = mgpu_big_reserve();
     int64_t tall_rows = std::max<int64_t>(32, big_reserve) * (int64_t)PANEL_THREADS;
     if (const char* e = getenv("RFLU_MGPU_TALL_ROWS")) tall_rows = atoll(e);     // debugging knobs
     std::vector<hipStream_t> Ucur(g->U);   // the stream that carried each device's previous update

@@ -310,6 +310,68 @@ int launch_iota_ipiv(Handle* h, int64_t* ipiv, int64_t k0, int64_t n)
 // kernels on monotonically increasing 64-bit counters: gate_signal publishes `value` when the stream reaches it (everything
 // before it in the stream has completed and released its writes), gate_wait holds its stream until a counter reaches `value`.
 // A waiter that sees no progress for ~2 s raises the panel timeout flag (info[1] bit 0) and lets its stream go on.
+// ---- do two streams share a hardware pipe? -----------------------------------------------------------------------------------
+// HSA queues are spread round-robin over the 4 pipes of the compute micro-engine, and a pipe serves one of its queues at a time: while
+// the head packet of one queue waits for its predecessor (every kernel of an in-order stream does), the other queues of that pipe are
+// not looked at.  Two BUSY streams on one pipe therefore take turns kernel by kernel (N=4096: 12 -> 20 ms when the update or the
+// side stream shares the critical path's pipe; which streams collide depends on how many queues the process created before).
+// The probe: stream a runs {spin for `ticks`, mark}, stream b runs {mark}, enqueued in that order.  On different pipes b's mark starts
+// while a is still spinning; on the same pipe it starts after a's spin has ended.
+__global__ void qprobe_spin_kernel(long long* out, long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    *out = (long long)wall_clock64();
+}
+__global__ void qprobe_mark_kernel(long long* out) { *out = (long long)wall_clock64(); }
+
+// slots: device memory for 3 stamps; returns 1 (shared pipe), 0 (independent) in *shared
+int queue_probe(hipStream_t a, hipStream_t b, long long* slots, long long* host3, int* shared)
+{
+    RFLU_HIP(hipStreamSynchronize(a));
+    RFLU_HIP(hipStreamSynchronize(b));
+    hipLaunchKernelGGL(qprobe_mark_kernel, dim3(1), dim3(1), 0, a, slots + 1);   // both queues exist and are warm
+    hipLaunchKernelGGL(qprobe_mark_kernel, dim3(1), dim3(1), 0, b, slots + 2);
+    RFLU_HIP(hipStreamSynchronize(a));
+    RFLU_HIP(hipStreamSynchronize(b));
+    hipLaunchKernelGGL(qprobe_spin_kernel, dim3(1), dim3(1), 0, a, slots + 0, 30000LL);   // 300 us at 100 MHz
+    hipLaunchKernelGGL(qprobe_mark_kernel, dim3(1), dim3(1), 0, a, slots + 1);
+    hipLaunchKernelGGL(qprobe_mark_kernel, dim3(1), dim3(1), 0, b, slots + 2);
+    RFLU_HIP(hipGetLastError());
+    RFLU_HIP(hipStreamSynchronize(a));
+    RFLU_HIP(hipStreamSynchronize(b));
+    RFLU_HIP(hipMemcpy(host3, slots, 3 * sizeof(long long), hipMemcpyDeviceToHost));
+    *shared = host3[2] >= host3[0] ? 1 : 0;
+    return RFLU_OK;
+}
+
+// Throughput form (the one validate_queues uses): `n` one-thread kernels on each of the two streams, enqueued alternately.  The
+// penalty of a shared pipe sets in after a few tens of kernels, so only the second half is timed:
+// *us_per_kernel = the slower stream's (last stamp - stamp of kernel n/2) / (n - 1 - n/2).  slots: 8 device words.
+int queue_probe_rate(hipStream_t a, hipStream_t b, int n, long long* slots, double* us_per_kernel)
+{
+    RFLU_HIP(hipStreamSynchronize(a));
+    RFLU_HIP(hipStreamSynchronize(b));
+    const int mid = n / 2;
+    // both queues are held back until everything is enqueued: what is timed is the rate at which two BACKLOGGED queues drain (with
+    // the host enqueueing at about the rate the GPU consumes, a shared pipe went unnoticed in one run of fourteen)
+    hipLaunchKernelGGL(qprobe_spin_kernel, dim3(1), dim3(1), 0, a, slots + 6, (long long)n * 800);   // 8 us per kernel pair, 100 MHz ticks
+    hipLaunchKernelGGL(qprobe_spin_kernel, dim3(1), dim3(1), 0, b, slots + 7, (long long)n * 800);
+    for (int i = 0; i < n; ++i) {
+        hipLaunchKernelGGL(qprobe_mark_kernel, dim3(1), dim3(1), 0, a, slots + (i < mid ? 4 : (i == mid ? 0 : 1)));
+        hipLaunchKernelGGL(qprobe_mark_kernel, dim3(1), dim3(1), 0, b, slots + (i < mid ? 5 : (i == mid ? 2 : 3)));
+    }
+    RFLU_HIP(hipGetLastError());
+    RFLU_HIP(hipStreamSynchronize(a));
+    RFLU_HIP(hipStreamSynchronize(b));
+    long long hs[4];
+    RFLU_HIP(hipMemcpy(hs, slots, sizeof(hs), hipMemcpyDeviceToHost));
+    const double d = double(n - 1 - mid);
+    const double ta = double(hs[1] - hs[0]) / 100.0 / d, tb = double(hs[3] - hs[2]) / 100.0 / d;
+    *us_per_kernel = ta > tb ? ta : tb;
+    return RFLU_OK;
+}
+
 __global__ void gate_signal_kernel(unsigned long long* flag, unsigned long long value, long long* stamp)
 {
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

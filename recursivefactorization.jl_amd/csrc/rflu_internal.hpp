@@ -53,6 +53,11 @@ struct Handle {
     hipStream_t ustreams[8] = {};     // ustreams[r]: CU mask leaving 32*r CUs to the critical path (r = 1..7)
     bool mask_failed = false;         // a CU-masked stream could not be created: plain streams may share a hardware queue, so the
                                       // device-side gates (which need the streams to run concurrently) are not used
+    std::vector<hipStream_t> parked_streams;   // masked streams that shared a pipe with a stream in use (validate_queues): kept idle
+    long long* qprobe_slots = nullptr;         // device: 4 stamps of the pipe probe
+    hipStream_t queues_ok_stream = nullptr;    // validate_queues: the caller's stream the masked streams were checked against
+    bool queues_ok_valid = false;
+    int queues_ok_count = 0;                   // ... and how many masked streams existed then
     hipStream_t pstreams[8] = {};     // pstreams[r]: the complement -- exactly those 32*r CUs (critical path of the update-bound phase)
     bool panel_attr_set[2][2] = {};        // [Float64|Float32][64|128 rows]: dynamic-LDS attribute of the small-workgroup leaves
     hipEvent_t tail_event = nullptr;       // column-major entry: the columns right of the first block column are still being
@@ -224,6 +229,8 @@ template <typename T>
 int launch_fill_uniform(Handle* h, T* A, int64_t m, int64_t n, int64_t ld, int row_major, uint64_t seed,
                         int64_t M_global, int64_t i0, int64_t j0, double diag_add);
 int launch_iota_ipiv(Handle* h, int64_t* ipiv, int64_t k0, int64_t n);
+int queue_probe(hipStream_t a, hipStream_t b, long long* slots, long long* host3, int* shared);   // laswp.hip: do two streams share a pipe?
+int queue_probe_rate(hipStream_t a, hipStream_t b, int n, long long* slots, double* us_per_kernel);
 int launch_gate_signal(Handle* h, unsigned long long* flag, unsigned long long value, long long* stamp = nullptr);   // laswp.hip: device-side stream gates
 int launch_gate_wait(Handle* h, const unsigned long long* flag, unsigned long long value);
 // butterfly.hip: A <- U' A V (column-major, in place) and x <- U' x (mode 0) / x <- V x (mode 1)

@@ -494,6 +494,33 @@ def main():
                                   "backward error ||A x - b|| / (||A|| ||x||) of x = V ((U'AV) \\ (U'b)), src/butterflylu.jl:45-55"},
         }
 
+    # ---- the reference's own boundary: a host array in, the factors back in it (src/lu.jl:116-121 pins the caller's arrays).  Not part
+    # of `value` (inputs resident in HBM); quoted so that the cost of the two PCIe crossings is on record.  The way back overlaps the
+    # factorization (driver.cpp: getrf_host); the way in cannot (the first update touches every column).
+    host_entry = None
+    if single and not args.no_extras and n >= 1024 and args.blocksize == 0:
+        regenerate(); barrier()
+        Ah = np.ascontiguousarray(A.cpu().numpy())   # the same n*n values in the same order: the library reads them column-major
+        if True:
+            ih = np.empty(n, dtype=np.int64)
+            infh = ctypes.c_int64(0)
+            keep = Ah.copy()
+            h.set_stream(None)
+            ts = []
+            for _ in range(3):                     # the first call pins the bounce buffers and faults the pages in
+                np.copyto(Ah, keep)
+                t0 = time.perf_counter()
+                h.call(f"rflu_getrf_{sfx}", n, n, ctypes.c_void_p(Ah.ctypes.data), n, ctypes.c_void_p(ih.ctypes.data if pivot else 0),
+                       pivot, 0, ctypes.byref(infh))
+                ts.append(time.perf_counter() - t0)
+            h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            hh = min(ts[1:])
+            host_entry = {"host_to_host_ms": round(1e3 * hh, 2), "factor_ms": round(ms_per_step, 3),
+                          "pcie_bytes_each_way": esz * n * n,
+                          "note": "rflu_getrf_* on a pageable host array (lu! of a host matrix): copy in, factor, factors and ipiv back in "
+                                  "the caller's array; best of two warm calls, wall clock around the call"}
+            del keep, Ah
+
     # ---- checks on the last factorization: residual on device (torch as an independent checker) ----
     check = {}
     if not args.no_check and single and n <= 32768:
@@ -573,6 +600,7 @@ def main():
             "laswp": laswp,
             "sweep": sweep,
             "variants": variants,
+            "host_entry": host_entry,
             "cpu_baseline": cpu,
             "check": check,
             "kernel_ms": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in kern.items()},

@@ -22,6 +22,7 @@
 
 #include "rflu_internal.hpp"
 #include <chrono>
+#include <thread>
 
 namespace rflu {
 
@@ -502,9 +503,9 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     // follows it, and is put back on every way out of this function.
     struct Restore { Handle* h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, h->stream};
     const hipStream_t userS = h->stream;
-    // Confining the critical path to the reserved CUs while the update is the bottleneck is worth 1.3 ms at N=16384 on its own,
-    // but it is a fourth queue next to {caller's stream, update stream, side stream of factor_leafwise}, and a factorization
-    // that uses four queues runs 25 % slower (DESIGN.md "queues"): off unless RFLU_CONFINE_ROWS asks for it.
+    // Confining the critical path to the reserved CUs while the update is the bottleneck: round 2 measured +1.3 ms in its favour,
+    // round 3 -2.4 ms against it with all four streams on pipes of their own (validate_queues; without that a fourth stream may share
+    // a pipe with one of the other three, which costs 25-60 %): off unless RFLU_CONFINE_ROWS asks for it.
     int64_t confine_rows = (int64_t)1 << 40;
     if (const char* e = getenv("RFLU_CONFINE_ROWS")) confine_rows = atoll(e);
     auto move_P = [&](hipStream_t to, int64_t b) -> int {
@@ -696,8 +697,10 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         uend_prev = b;
         Uprev = U;
         prev_overlapped = true;
+        if (h->progress) RFLU_TRY(h->progress(j0));   // block column b-1's last piece (restB) went out after panel b: rows above j0 are settled
     }
     RFLU_TRY(flush_pending());
+    if (h->progress) RFLU_TRY(h->progress(std::min(std::min(nblk, b_end) * W, mn)));
     RFLU_TRY(move_P(userS, nblk));
     f.sw_lo = 0;
     f.sw_hi = -1;
@@ -726,9 +729,8 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
 //        (evU1[b]) -- exactly the update stream of factor_lookahead.
 // Queues: the critical path stays on the caller's stream and there is ONE side stream (the next block column's part of the first
 // leaf of a block waits for evU1 between two gates of its own).  An earlier version with two side streams and the critical path
-// on a third, CU-confined stream ran at 115-118 ms for N=16384 instead of 88: a factorization that uses four or more queues
-// is served 25-30 % slower whatever they do (the same happened to factor_lookahead with one extra stream; idle streams that
-// are never used do not count; rocprofv3 hides the effect -- DESIGN.md "queues").  hipEvent edges per leaf cost 40-50 us of
+// on a third, CU-confined stream ran at 115-118 ms for N=16384 instead of 88 -- two of its streams shared a hardware pipe, as round 3
+// found out (validate_queues now places every stream; with four streams there is no pipe to spare).  hipEvent edges per leaf cost 40-50 us of
 // bubble per record/wait on the hot stream, hipStreamWaitValue64/WriteValue64 were slower still: hence the device-side gates.
 // Measured (Float64, ms): N=4096 13.6 -> 12.0, N=8192 29.7 -> 26.8, N=12288 51.6 -> 49.6; N=16384 whole matrix 88.3, from the
 // first panel of <= 8192 rows on (after factor_lookahead) 84.8 vs 86.1.
@@ -820,7 +822,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         const int64_t bend = std::min(j0 + W, n), wend = std::min(j0 + 2 * W, n);
         const int res = reserve_for(m - j0);
         // The side stream is the update stream of the 64-CU reservation: it keeps away from the panel's 32 CUs like U does,
-        // and a taller matrix has already used it for its first block columns -- no fourth queue (see the header comment).
+        // and a taller matrix has already used it for its first block columns -- one queue less to place (validate_queues).
         if (res != 32) { set_error("factor_leafwise: panel of %lld rows needs more than 32 CUs", (long long)(m - j0)); return RFLU_ERR_ARG; }
         hipStream_t S;
         RFLU_TRY(get_ustream(h, swap_su ? 32 : 64, &S));
@@ -910,6 +912,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         RFLU_TRY(update(U, j0, jb, p1e, n));
         RFLU_TRY(record_on(U, evUend(b)));
         Uprev = U;
+        if (h->progress) RFLU_TRY(h->progress(je));
     }
     if (P != userS) {
         RFLU_TRY(record_on(P, EX + (size_t)nblk));
@@ -1376,6 +1379,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     if (m < n && !fat_tail_done)  // fat matrix: AR <- L^-1 AR (src/lu.jl:148-154; interchanges already applied there)
         RFLU_TRY(trsm_rec<T>(h, m, n - m, R, ld, R + m, ld, f.linv_at(0)));
 
+    if (h->before_sync) RFLU_TRY(h->before_sync());
     RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     RFLU_HIP(hipStreamSynchronize(h->stream));
     RFLU_TRY(panel_flags_status(h));
@@ -1437,7 +1441,7 @@ static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int6
     }
     h->tail_event = nullptr;
     RFLU_TRY(rc_f);
-    RFLU_TRY(launch_transpose<T>(h, n, m, R, ldr, A, lda));
+    if (!h->out_done) RFLU_TRY(launch_transpose<T>(h, n, m, R, ldr, A, lda));   // (the host entry has taken the factors out piece by piece)
     RFLU_HIP(hipStreamSynchronize(h->stream));
     return RFLU_OK;
 }
@@ -1463,12 +1467,153 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
         h->ipiv_cap = (size_t)mn;
     }
     T* dA = static_cast<T*>(h->hostA_dev);
+    const auto t_call = std::chrono::steady_clock::now();
     RFLU_HIP(hipMemcpy2DAsync(dA, (size_t)m * sizeof(T), A, (size_t)lda * sizeof(T), (size_t)m * sizeof(T), (size_t)n,
                               hipMemcpyHostToDevice, h->stream));
+    const auto t_in = std::chrono::steady_clock::now();
     const bool want_ipiv = (ipiv != nullptr);
+    // ---- the way back, overlapped -------------------------------------------------------------------------------------------
+    // Rows [j0, j0 + W) of the factors are final as soon as block column b has been applied everywhere (later interchanges only
+    // touch rows below), and in the row-major workspace a block of rows is one contiguous piece.  The block-column schedules report
+    // how far that has got while they enqueue (Handle::progress); per chunk of rows the events of every stream are kept.  When
+    // everything is enqueued (Handle::before_sync: 7 ms into an 80 ms factorization at N=16384) the calling thread -- which would only
+    // wait now -- brings the chunks home on a stream of its own: wait for the chunk's events, transpose its rows into a contiguous
+    // column-major piece of the staging copy, one contiguous copy into a pinned bounce buffer of the handle, and from there into the
+    // caller's columns with a few host threads while the next chunk is on the link.  Chunks are 2048 rows while the factorization
+    // has far to go and one block column at the end, so that little is left when the last leaf finishes.
+    // Two things this needs: (1) the fourth stream on a hardware pipe of its own like the other three (validate_queues; round 3
+    // first built this without and measured +26 ms instead of -30); (2) our own bounce buffers: a device-to-host copy into PAGEABLE
+    // memory issued next to the running factorization returns only when the factorization has finished (the same call next to a
+    // single long kernel does not wait: scripts/probes/d2h_block.hip), so the runtime's staging is of no use here.
+    // RFLU_HOST_EARLY_OUT=0: the round-2 sequence (everything after the factorization).
+    static const int64_t chunk = [] { const char* e = getenv("RFLU_HOST_EARLY_OUT"); return e ? atoll(e) : 512; }();
+    const int64_t W0 = blocksize == 0 ? default_blocksize(mn) : blocksize;
+    const bool early = chunk >= 64 && !h->prof && h->num_cus == 256 && mn >= 8192 && W0 > 0 && W0 < mn;
+    struct Mark { int64_t r1; std::vector<hipEvent_t> ev; };
+    std::vector<Mark> marks;
+    size_t ev_used = 0;
+    hipStream_t C = nullptr;
+    struct Reset { Handle* h; ~Reset() { h->progress = nullptr; h->before_sync = nullptr; h->out_done = false; } } reset{h};
+    if (early) {
+        RFLU_TRY(get_ustream(h, 96, &C));   // a masked stream = a queue of its own that validate_queues can place
+        if (h->mask_failed) C = nullptr;
+    }
+    if (early && C) {
+        const size_t bounce_bytes = (size_t)std::min(chunk, m) * (size_t)n * sizeof(T);
+        if (h->bounce_bytes < bounce_bytes) {
+            for (int i = 0; i < 2; ++i) {
+                if (h->bounce[i]) RFLU_HIP(hipHostFree(h->bounce[i]));
+                h->bounce[i] = nullptr;
+            }
+            h->bounce_bytes = 0;
+            for (int i = 0; i < 2; ++i) RFLU_HIP(hipHostMalloc(&h->bounce[i], bounce_bytes));
+            h->bounce_bytes = bounce_bytes;
+        }
+        const hipStream_t user = h->stream;
+        auto new_event = [h, &ev_used](hipEvent_t* e) -> int {
+            if (ev_used == h->out_events.size()) {
+                hipEvent_t x;
+                RFLU_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+                h->out_events.push_back(x);
+            }
+            *e = h->out_events[ev_used++];
+            return RFLU_OK;
+        };
+        auto mark_all = [h, user, new_event](std::vector<hipEvent_t>& out) -> int {
+            auto rec = [&](hipStream_t st) -> int {
+                hipEvent_t e;
+                RFLU_TRY(new_event(&e));
+                RFLU_HIP(hipEventRecord(e, st));
+                out.push_back(e);
+                return RFLU_OK;
+            };
+            RFLU_TRY(rec(user));
+            if (h->stream != user) RFLU_TRY(rec(h->stream));
+            for (int r = 1; r < 8; ++r) {
+                if (r != 3 && h->ustreams[r]) RFLU_TRY(rec(h->ustreams[r]));
+                if (h->pstreams[r] && h->pstreams[r] != h->stream) RFLU_TRY(rec(h->pstreams[r]));
+            }
+            return RFLU_OK;
+        };
+        h->progress = [&marks, mark_all, m](int64_t r) -> int {
+            const int64_t have = marks.empty() ? 0 : marks.back().r1;
+            r = std::min(r, m);
+            // far from the end: whole chunks; within one chunk of the end: every report (one block column at a time)
+            if (r <= have || (r - have < chunk && r + chunk < m)) return RFLU_OK;
+            marks.push_back(Mark{std::min(r, have + chunk), {}});
+            return mark_all(marks.back().ev);
+        };
+        h->before_sync = [&, mark_all, new_event]() -> int {
+            {   // whatever is left (rows below the square part of a tall matrix included) is final when everything is: in chunk-sized pieces
+                int64_t have = marks.empty() ? 0 : marks.back().r1;
+                if (have < m) {
+                    std::vector<hipEvent_t> all;
+                    RFLU_TRY(mark_all(all));
+                    while (have < m) {
+                        have = std::min(m, have + chunk);
+                        marks.push_back(Mark{have, all});
+                    }
+                }
+            }
+            const int64_t ldr = workspace_ld(n);
+            const T* R = static_cast<const T*>(h->work);
+            const hipStream_t saved = h->stream;
+            const bool trace = getenv("RFLU_HOST_TRACE") != nullptr;
+            auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+            if (trace) fprintf(stderr, "[rflu] host entry: enqueue done %.1f ms after the call (%.1f after the copy in), %zu chunks\n", since(t_call), since(t_in), marks.size());
+            const size_t nchunks = marks.size();
+            std::vector<hipEvent_t> landed(nchunks);
+            std::vector<int64_t> start(nchunks);
+            {
+                int64_t r0 = 0;
+                for (size_t k = 0; k < nchunks; ++k) { start[k] = r0; r0 = marks[k].r1; }
+            }
+            auto send = [&](size_t k) -> int {   // chunk k: events -> transpose into a contiguous piece of the staging copy -> bounce buffer
+                const int64_t r0 = start[k], rows = marks[k].r1 - r0;
+                for (hipEvent_t e : marks[k].ev)
+                    if (hipStreamWaitEvent(C, e, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); return RFLU_ERR_HIP; }
+                h->stream = C;
+                const int rc = launch_transpose<T>(h, n, rows, R + r0 * ldr, ldr, dA + r0 * n, rows);
+                h->stream = saved;
+                RFLU_TRY(rc);
+                RFLU_HIP(hipMemcpyAsync(h->bounce[k & 1], dA + r0 * n, (size_t)rows * (size_t)n * sizeof(T), hipMemcpyDeviceToHost, C));
+                RFLU_TRY(new_event(&landed[k]));
+                RFLU_HIP(hipEventRecord(landed[k], C));
+                return RFLU_OK;
+            };
+            static const int nthreads = [] {
+                const char* e = getenv("RFLU_HOST_THREADS");
+                const int v = e ? atoi(e) : 8;
+                return std::max(1, std::min(v, 64));
+            }();
+            for (size_t k = 0; k < std::min<size_t>(2, nchunks); ++k) RFLU_TRY(send(k));
+            for (size_t k = 0; k < nchunks; ++k) {
+                RFLU_HIP(hipEventSynchronize(landed[k]));
+                const int64_t r0 = start[k], rows = marks[k].r1 - r0;
+                const T* src = static_cast<const T*>(h->bounce[k & 1]);
+                auto scatter = [&](int64_t j0, int64_t j1) {
+                    for (int64_t j = j0; j < j1; ++j) memcpy(A + j * lda + r0, src + j * rows, (size_t)rows * sizeof(T));
+                };
+                if (nthreads == 1 || (size_t)rows * (size_t)n * sizeof(T) < ((size_t)8 << 20)) {
+                    scatter(0, n);
+                } else {
+                    std::vector<std::thread> pool;
+                    const int64_t per = (n + nthreads - 1) / nthreads;
+                    for (int t = 1; t < nthreads; ++t) pool.emplace_back(scatter, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
+                    scatter(0, std::min<int64_t>(n, per));
+                    for (std::thread& th : pool) th.join();
+                }
+                if (trace) fprintf(stderr, "[rflu] host entry: rows [%lld, %lld) home at %.1f ms\n", (long long)r0, (long long)marks[k].r1, since(t_call));
+                if (k + 2 < nchunks) RFLU_TRY(send(k + 2));   // its bounce buffer is free again
+            }
+            h->out_done = true;
+            return RFLU_OK;
+        };
+    }
     RFLU_TRY(getrf_cm_dev<T>(h, m, n, dA, m, (pivot || want_ipiv) ? h->ipiv_dev : nullptr, pivot, blocksize, info));
-    RFLU_HIP(hipMemcpy2DAsync(A, (size_t)lda * sizeof(T), dA, (size_t)m * sizeof(T), (size_t)m * sizeof(T), (size_t)n,
-                              hipMemcpyDeviceToHost, h->stream));
+    if (!h->out_done)
+        RFLU_HIP(hipMemcpy2DAsync(A, (size_t)lda * sizeof(T), dA, (size_t)m * sizeof(T), (size_t)m * sizeof(T), (size_t)n,
+                                  hipMemcpyDeviceToHost, h->stream));
     if (want_ipiv)
         RFLU_HIP(hipMemcpyAsync(ipiv, h->ipiv_dev, (size_t)mn * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     RFLU_HIP(hipStreamSynchronize(h->stream));
@@ -1554,10 +1699,9 @@ int rflu_create(rflu_handle_t* handle, int device)
     h->stream = h->own_stream;
     RFLU_HIP(hipMalloc((void**)&h->info_dev, 2 * sizeof(int64_t)));
     if (const char* e = getenv("RFLU_DUMMY_QUEUES")) {
-        // measurement hook (scripts/queue_collision.py): k extra streams created AND USED here, before the update / side streams
-        // exist.  How many hardware queues the process has touched changes how the schedules' three queues are served (round 2's
-        // "fourth queue" effect): N=16384 82 ms with k = 0..1, 108-114 ms with k = 2..5 -- although kernels of the three streams
-        // still overlap (probed).  Known sensitivity, see DESIGN.md "queues".
+        // measurement / test hook (scripts/queue_collision.py, tests/test_gpu_queues.py): k extra streams created AND USED here,
+        // before the update / side streams exist, so that those get other queue indices -- and with them other hardware pipes -- than
+        // in a fresh process.  Without validate_queues (RFLU_QUEUE_CHECK=0): N=16384 80 ms or 108-113 ms depending on k.
         for (int i = 0; i < atoi(e); ++i) {
             hipStream_t d;
             RFLU_HIP(hipStreamCreateWithFlags(&d, hipStreamNonBlocking));
@@ -1611,6 +1755,8 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->info_pinned) (void)hipHostFree(h->info_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->out_events) (void)hipEventDestroy(e);
+    for (void* b : h->bounce) if (b) (void)hipHostFree(b);
     for (hipStream_t ps : h->parked_streams)
         if (ps) (void)hipStreamDestroy(ps);
     if (h->qprobe_slots) (void)hipFree(h->qprobe_slots);
@@ -2093,8 +2239,8 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
     // The NEXT owner factors block column b+1 next to its own share of update b, which is only 1/D of the bulk: it can afford
     // to leave the panel as many CUs as its cooperating workgroups need.  Up to 32 workgroups (16384 rows): the usual 32-CU
     // reservation; up to `big_reserve` CUs (default 128 = 65536 rows): that device runs update b on the update stream of the big
-    // reservation (ONE extra stream per device: panel stream, 32-CU mask, big mask -- the fourth queue costs 25 %, DESIGN.md
-    // "queues").  Only a panel that needs even more is factored BEFORE the owner's bulk update (round 2 did that from 16384
+    // reservation (ONE extra stream per device: panel stream, 32-CU mask, big mask -- three streams on three of the four hardware
+    // pipes, placed by validate_queues).  Only a panel that needs even more is factored BEFORE the owner's bulk update (round 2 did that from 16384
     // rows on: at N=65536 over 8 GPUs 96 of 128 block columns, ~0.3 s of un-overlapped panels).
     const int64_t big_reserve = mgpu_big_reserve();
     int64_t tall_rows = std::max<int64_t>(32, big_reserve) * (int64_t)PANEL_THREADS;

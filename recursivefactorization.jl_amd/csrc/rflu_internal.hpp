@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
 
 #include "../../include/rflu.h"
@@ -53,6 +54,13 @@ struct Handle {
     hipStream_t ustreams[8] = {};     // ustreams[r]: CU mask leaving 32*r CUs to the critical path (r = 1..7)
     bool mask_failed = false;         // a CU-masked stream could not be created: plain streams may share a hardware queue, so the
                                       // device-side gates (which need the streams to run concurrently) are not used
+    // host-pointer entry (getrf_host): finished block rows travel back while the rest is still being factored
+    std::function<int(int64_t)> progress;      // called by the block-column schedules: every kernel that writes rows [0, r) is enqueued
+    std::function<int()> before_sync;          // called by getrf_rm when the whole factorization is enqueued, before it waits for it
+    bool out_done = false;                     // set by before_sync: the factors are already in the caller's buffer
+    std::vector<hipEvent_t> out_events;        // event pool of that path
+    void* bounce[2] = {};                      // pinned bounce buffers of that path (one chunk of rows each)
+    size_t bounce_bytes = 0;
     std::vector<hipStream_t> parked_streams;   // masked streams that shared a pipe with a stream in use (validate_queues): kept idle
     long long* qprobe_slots = nullptr;         // device: 4 stamps of the pipe probe
     hipStream_t queues_ok_stream = nullptr;    // validate_queues: the caller's stream the masked streams were checked against

@@ -1,0 +1,70 @@
+"""Host-pointer entry at sizes where the way back overlaps the factorization (driver.cpp: getrf_host, n >= 8192): finished block
+rows leave through a fourth stream, pinned bounce buffers and a threaded scatter into the caller's columns.  Same factors, pivots
+and info as the device entry, to the bit -- the two differ only in how the result travels."""
+import ctypes
+import numpy as np
+import pytest
+import torch
+
+import recursivefactorization.jl_amd as rf
+from recursivefactorization.jl_amd import _ffi
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_reference(A, pivot, bs):
+    W = torch.from_numpy(np.ascontiguousarray(A.T)).to("cuda:0").T      # column-major device view
+    F = rf.lu_(W, None, pivot, check=False, blocksize=bs)
+    ip = F.ipiv.cpu().numpy() if pivot else None
+    return F.factors.cpu().numpy(), ip, F.info
+
+
+@pytest.mark.parametrize("m,n,dtype,pivot,bs", [
+    (8192, 8192, np.float64, True, None),     # all leaf-wise
+    (12288, 12288, np.float64, True, None),   # block-column lookahead first, then leaf-wise
+    (10000, 8200, np.float64, True, None),    # tall: the rows below the square part are final only at the end
+    (8192, 9000, np.float64, True, 256),      # fat
+    (8192, 8192, np.float32, True, None),
+    (8192, 8192, np.float64, False, None),    # NoPivot
+])
+def test_host_entry_matches_device_entry(m, n, dtype, pivot, bs, monkeypatch):
+    A = O.fill_uniform(m, n, 5 + m + n, dtype)
+    if not pivot:
+        A[np.arange(min(m, n)), np.arange(min(m, n))] += 10.0
+    ref, ipr, infr = _device_reference(A, pivot, bs)
+    variants = [{}]
+    if (m, n, dtype, pivot) == (8192, 8192, np.float64, True):   # other chunkings / thread counts, and the plain sequence
+        variants += [{"RFLU_HOST_EARLY_OUT": "1024", "RFLU_HOST_THREADS": "3"}, {"RFLU_HOST_EARLY_OUT": "0"}]
+    for env in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        H = np.asfortranarray(A.copy())
+        F = rf.lu_(H, None, pivot, check=False, blocksize=bs)
+        assert F.info == infr
+        assert np.array_equal(np.asarray(F.factors), ref), env
+        if pivot:
+            assert np.array_equal(np.asarray(F.ipiv), ipr)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_host_entry_with_a_column_stride_and_reuse():
+    """lda > m (a view into a taller buffer), the same handle and bounce buffers used for a second, smaller matrix."""
+    n, lda = 8192, 8192 + 24
+    A = O.fill_uniform(n, n, 77, np.float64)
+    ref, ipr, _ = _device_reference(A, True, None)
+    buf = np.full((lda, n), np.nan, order="F")
+    buf[:n, :] = A
+    h = _ffi.default_handle(0)
+    h.set_stream(None)
+    ipiv = np.empty(n, dtype=np.int64)
+    info = ctypes.c_int64(0)
+    h.call("rflu_getrf_f64", n, n, ctypes.c_void_p(buf.ctypes.data), lda, ctypes.c_void_p(ipiv.ctypes.data), 1, 0, ctypes.byref(info))
+    assert info.value == 0
+    assert np.array_equal(buf[:n, :], ref) and np.array_equal(ipiv, ipr)
+    assert np.isnan(buf[n:, :]).all()          # nothing written below the matrix
+    B = np.asfortranarray(A[:8192 - 512, :8192 - 512].copy())
+    refB, ipB, _ = _device_reference(A[:8192 - 512, :8192 - 512], True, None)
+    F = rf.lu_(B, None, True, check=False)
+    assert np.array_equal(np.asarray(F.factors), refB) and np.array_equal(np.asarray(F.ipiv), ipB)

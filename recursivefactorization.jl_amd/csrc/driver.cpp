@@ -407,7 +407,9 @@ static int validate_queues(Handle* h)
     if (off) return RFLU_OK;
     int created = 0;
     for (int r = 1; r < 8; ++r) created += (h->ustreams[r] != nullptr) + (h->pstreams[r] != nullptr);
-    if (h->queues_ok_stream == h->stream && h->queues_ok_valid && h->queues_ok_count == created) return RFLU_OK;
+    if (h->queues_ok_count != created) h->queues_ok_streams.clear();
+    for (hipStream_t ok : h->queues_ok_streams)
+        if (ok == h->stream) return RFLU_OK;   // (a host program that alternates between a few streams is checked once per stream)
     if (!h->qprobe_slots) RFLU_HIP(hipMalloc((void**)&h->qprobe_slots, 8 * sizeof(long long)));
     const hipStream_t P = h->stream;
     constexpr int NPROBE = 128;   // the second half is timed (queue_probe_rate)
@@ -431,6 +433,7 @@ static int validate_queues(Handle* h)
             if (worst <= limit) break;
             if (attempt == 7) break;   // keep the last one: never fail a factorization over placement
             h->parked_streams.push_back(*slot);
+            h->queues_ok_streams.clear();   // what was accepted next to other caller streams is no longer what is in use
             *slot = nullptr;
             hipStream_t fresh;
             if (complement) RFLU_TRY(get_pstream(h, 32 * r, &fresh));
@@ -444,9 +447,10 @@ static int validate_queues(Handle* h)
         if (h->ustreams[r]) RFLU_TRY(settle(&h->ustreams[r], r, false));
     for (int r = 1; r < 8; ++r)
         if (h->pstreams[r]) RFLU_TRY(settle(&h->pstreams[r], r, true));
-    h->queues_ok_stream = P;
-    h->queues_ok_valid = true;
-    h->queues_ok_count = created;
+    if (h->queues_ok_streams.size() >= 8) h->queues_ok_streams.erase(h->queues_ok_streams.begin());
+    h->queues_ok_streams.push_back(P);
+    h->queues_ok_count = 0;
+    for (int r = 1; r < 8; ++r) h->queues_ok_count += (h->ustreams[r] != nullptr) + (h->pstreams[r] != nullptr);
     return RFLU_OK;
 }
 

@@ -63,9 +63,8 @@ struct Handle {
     size_t bounce_bytes = 0;
     std::vector<hipStream_t> parked_streams;   // masked streams that shared a pipe with a stream in use (validate_queues): kept idle
     long long* qprobe_slots = nullptr;         // device: 4 stamps of the pipe probe
-    hipStream_t queues_ok_stream = nullptr;    // validate_queues: the caller's stream the masked streams were checked against
-    bool queues_ok_valid = false;
-    int queues_ok_count = 0;                   // ... and how many masked streams existed then
+    std::vector<hipStream_t> queues_ok_streams;   // validate_queues: caller streams the masked streams in use have been checked against
+    int queues_ok_count = 0;                      // ... and how many masked streams existed then
     hipStream_t pstreams[8] = {};     // pstreams[r]: the complement -- exactly those 32*r CUs (critical path of the update-bound phase)
     bool panel_attr_set[2][2] = {};        // [Float64|Float32][64|128 rows]: dynamic-LDS attribute of the small-workgroup leaves
     hipEvent_t tail_event = nullptr;       // column-major entry: the columns right of the first block column are still being

@@ -51,3 +51,29 @@ def test_streams_end_up_on_different_pipes_whatever_the_queue_history():
             ms = min(ms, _run(k)[0])
         assert ms < 1.4 * base_ms, (k, ms, base_ms, checks)
     assert replaced >= 1, "none of the three histories put a stream on the critical path's pipe: the test no longer tests anything"
+
+
+ALTERNATE = r"""
+import torch
+import recursivefactorization.jl_amd as rf
+n = 2048
+A = torch.rand((n, n), dtype=torch.float64, device="cuda").T.contiguous().T
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+for i in range(8):
+    with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+        W = A.clone()
+        F = rf.lu_(W, None, True, check=False)
+        assert F.info == 0
+torch.cuda.synchronize()
+print("DONE")
+"""
+
+
+def test_alternating_caller_streams_are_checked_once_each():
+    """The placement is cached per caller stream: a program that alternates between two streams pays for two checks (three if the
+    second one forced a replacement), not for one per call."""
+    env = dict(os.environ, RFLU_QUEUE_TRACE="1", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-c", ALTERNATE], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0 and "DONE" in p.stdout, p.stderr[-2000:]
+    rounds = len(re.findall(r"queue check ustream\[1\] attempt 0", p.stderr))
+    assert 1 <= rounds <= 3, (rounds, p.stderr[-3000:])

@@ -1603,8 +1603,16 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
                 } else {
                     std::vector<std::thread> pool;
                     const int64_t per = (n + nthreads - 1) / nthreads;
-                    for (int t = 1; t < nthreads; ++t) pool.emplace_back(scatter, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
+                    int64_t done_to = std::min<int64_t>(n, per);   // columns [per, done_to) have a thread; no exception leaves this C entry
+                    try {
+                        for (int t = 1; t < nthreads; ++t) {
+                            pool.emplace_back(scatter, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
+                            done_to = std::min<int64_t>(n, (t + 1) * per);
+                        }
+                    } catch (...) {
+                    }
                     scatter(0, std::min<int64_t>(n, per));
+                    if (done_to < n) scatter(done_to, n);           // the threads that could not be started
                     for (std::thread& th : pool) th.join();
                 }
                 if (trace) fprintf(stderr, "[rflu] host entry: rows [%lld, %lld) home at %.1f ms\n", (long long)r0, (long long)marks[k].r1, since(t_call));

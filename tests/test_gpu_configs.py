@@ -164,6 +164,21 @@ def test_deep_schedule_matches_default(n, bs, env, monkeypatch):
     assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
 
 
+@pytest.mark.parametrize("n,dtype", [(4096, np.float64), (3000, np.float64), (6144, np.float64), (4096, np.float32)])
+def test_xcd_local_short_panels_are_bit_identical(n, dtype, monkeypatch):
+    """Panels of at most 4096 rows run with all participants on one XCD and plain-store records (panel.hip: RFLU_PANEL_LOCAL_ROWS);
+    taller ones, and everything with RFLU_PANEL_LOCAL_ROWS=0, with write-through records on any placement.  Same arithmetic, same
+    order: identical factors and pivots."""
+    monkeypatch.setenv("RFLU_PANEL_LOCAL_ROWS", "0")
+    A, F = _factor(n, dtype, True, 0)
+    monkeypatch.delenv("RFLU_PANEL_LOCAL_ROWS")
+    for _ in range(2):
+        _, G = _factor(n, dtype, True, 0)
+        assert F.info == G.info == 0
+        assert torch.equal(F.ipiv, G.ipiv)
+        assert torch.equal(F.factors, G.factors)
+
+
 @pytest.mark.parametrize("m,n,bs,dtype,pivot", [
     (3000, 2048, 128, np.float64, True),     # tall: panels of 3000 .. 952 rows
     (2048, 3000, 256, np.float64, True),     # fat: the windows of the last block column reach into the tail (src/lu.jl:148-154)

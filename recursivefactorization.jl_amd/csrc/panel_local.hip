@@ -574,7 +574,13 @@ int launch_panel_local(Handle* h, const PanelArgs<T>& p0, int stride, int sel, i
     la.sel = sel;
     la.want_xcc = want_xcc;
     const int64_t rows = (int64_t)p0.m - p0.r0;
-    const int rpw = local ? (((rows + 255) / 256 <= 32 && !h->coop_launch) ? 256 : 512) : panel_local_rows_per_wg(h, rows);
+    int rpw = local ? (((rows + 255) / 256 <= 32 && !h->coop_launch) ? 256 : 512) : panel_local_rows_per_wg(h, rows);
+    // XCD-local: at most 16 participants (the other 7/8 of the launch have to find a home too), so the short workgroups whose
+    // per-column chain is shorter serve panels of <= 1024 / 2048 rows (N=2048 5.38 -> 5.11 ms, N=4096 11.01 -> 10.74, N=8192 25.47 -> 25.2)
+    if (local && !h->coop_launch) {
+        if ((rows + 63) / 64 <= 16) rpw = 64;
+        else if ((rows + 127) / 128 <= 16) rpw = 128;
+    }
     la.p.G = (int)((rows + rpw - 1) / rpw);
     const bool pw4 = rpw == 256;
     const dim3 grid((unsigned)(la.p.G * stride));
@@ -589,15 +595,23 @@ int launch_panel_local(Handle* h, const PanelArgs<T>& p0, int stride, int sel, i
         // slowed by them (N=4096: 13.3 ms without, 12.7 ms with); asking for more LDS than a CU with a GEMM workgroup (70 KB
         // each) has left sends it to an empty CU -- one of those the update stream's mask keeps free.
         static const int ballast = [] { const char* e = getenv("RFLU_PANEL_BALLAST"); return e ? atoi(e) : 96 * 1024; }();
-        bool& attr_set = h->panel_attr_set[sizeof(T) == 8 ? 0 : 1][rpw == 64 ? 0 : 1];   // per handle = per device
-        const void* fn = rpw == 64 ? reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 1>)
-                                   : reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 2>);
+        // (the XCD-local variants too: without it N=4096 11.12-11.15 ms, with it 10.74-10.82)
+        bool& attr_set = h->panel_attr_set[local ? 1 : 0][sizeof(T) == 8 ? 0 : 1][rpw == 64 ? 0 : 1];   // per handle = per device
+        const void* fn = local ? (rpw == 64 ? reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, true, 1>)
+                                            : reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, true, 2>))
+                               : (rpw == 64 ? reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 1>)
+                                            : reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 2>));
         if (!attr_set && ballast > 0) {
             RFLU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ballast));
             attr_set = true;
         }
-        if (rpw == 64) hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 1>), grid, dim3(1 * 64 + 64), (size_t)ballast, h->stream, la);
-        else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 2>), grid, dim3(2 * 64 + 64), (size_t)ballast, h->stream, la);
+        if (local) {
+            if (rpw == 64) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true, 1>), grid, dim3(1 * 64 + 64), (size_t)ballast, h->stream, la);
+            else hipLaunchKernelGGL((panel_pivot_local_kernel<T, true, 2>), grid, dim3(2 * 64 + 64), (size_t)ballast, h->stream, la);
+        } else {
+            if (rpw == 64) hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 1>), grid, dim3(1 * 64 + 64), (size_t)ballast, h->stream, la);
+            else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 2>), grid, dim3(2 * 64 + 64), (size_t)ballast, h->stream, la);
+        }
         RFLU_HIP(hipGetLastError());
         return RFLU_OK;
     }

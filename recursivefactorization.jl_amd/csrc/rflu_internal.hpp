@@ -66,7 +66,7 @@ struct Handle {
     std::vector<hipStream_t> queues_ok_streams;   // validate_queues: caller streams the masked streams in use have been checked against
     int queues_ok_count = 0;                      // ... and how many masked streams existed then
     hipStream_t pstreams[8] = {};     // pstreams[r]: the complement -- exactly those 32*r CUs (critical path of the update-bound phase)
-    bool panel_attr_set[2][2] = {};        // [Float64|Float32][64|128 rows]: dynamic-LDS attribute of the small-workgroup leaves
+    bool panel_attr_set[2][2][2] = {};     // [any placement|XCD-local][Float64|Float32][64|128 rows]: dynamic-LDS attribute of the small-workgroup leaves
     hipEvent_t tail_event = nullptr;       // column-major entry: the columns right of the first block column are still being
                                            // transposed on the update stream; set = pending, consumed by getrf_rm
     hipEvent_t tail_event_obj = nullptr, tail_fork_obj = nullptr;

@@ -980,7 +980,9 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
         // two-trip kernel above, which also serves taller panels: measured 0.5 % faster there)
         static const bool pipe = [] { const char* e = getenv("RFLU_PIPE"); return e == nullptr || e[0] != '0'; }();
         // pipelined leaf with a communication wave (panel_local.hip); one header per lane of that wave: at most 64 workgroups
-        if (h->panel_local > 0 && p.G >= 2 && p.G <= std::min(h->panel_local_maxg, 64)) {
+        static const int64_t local_min = [] { const char* e = getenv("RFLU_PANEL_LOCAL_MIN"); return e ? atoll(e) : 256; }();   // panels of 257..512 rows: 8 workgroups of 64 rows on one XCD instead of the one-workgroup leaf (N=1024 2.59 -> 2.51 ms)
+        const bool tiny_local = h->panel_local == 2 && h->num_cus == 256 && rows > local_min && rows <= 512 && !h->coop_launch;
+        if (h->panel_local > 0 && (p.G >= 2 || tiny_local) && p.G <= std::min(h->panel_local_maxg, 64)) {
             // Panels of at most 4096 rows (<= 16 workgroups of 256 rows) run the XCD-local variant: all participants on ONE XCD, plain-store
             // records that stay in that XCD's L2, a 0.34 us hop instead of 0.56-0.75.  The launch has 8 G workgroups of which the 7 G on
             // the other XCDs exit at once; they still have to be placed, which next to a big update costs more than the hop saves (N=8192
@@ -988,7 +990,7 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
             // alone: N=2048 5.76 -> 5.39 ms, N=4096 11.97 -> 11.02, N=8192 26.48 -> 25.54, N=16384 80.46 -> 79.49 (6144 rows: 26.8 at
             // N=8192).  RFLU_PANEL_LOCAL_ROWS=0 switches it off, RFLU_PANEL_LOCAL=1 forces it for every panel.
             const int64_t local_rows = [] { const char* e = getenv("RFLU_PANEL_LOCAL_ROWS"); return e ? atoll(e) : 4096; }();   // (read per launch: tests switch it)
-            const bool loc = h->panel_local == 1 || (h->num_cus == 256 && rows <= local_rows && rows > 512);
+            const bool loc = h->panel_local == 1 || (h->num_cus == 256 && rows <= local_rows && (rows > 512 || tiny_local));
             RFLU_TRY(launch_panel_local<T>(h, p, loc ? 8 : 1, loc ? h->panel_xcc : 0, loc ? h->panel_xcc : -1, loc));
             return RFLU_OK;
         }

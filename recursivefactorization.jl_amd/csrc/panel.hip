@@ -989,7 +989,9 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
             // with every panel local: 31.9 vs 26.4 ms) -- but not once the panel is this short and the update streams leave most CUs
             // alone: N=2048 5.76 -> 5.39 ms, N=4096 11.97 -> 11.02, N=8192 26.48 -> 25.54, N=16384 80.46 -> 79.49 (6144 rows: 26.8 at
             // N=8192).  RFLU_PANEL_LOCAL_ROWS=0 switches it off, RFLU_PANEL_LOCAL=1 forces it for every panel.
-            const int64_t local_rows = [] { const char* e = getenv("RFLU_PANEL_LOCAL_ROWS"); return e ? atoll(e) : 4096; }();   // (read per launch: tests switch it)
+            // Float32: the update is half as heavy, the 32 participants of an 8192-row panel still find their XCD (N=16384 61.9 -> 59.9-60.7 ms,
+            // N=8192 22.45 -> 22.18; 12288 rows: 62.1)
+            const int64_t local_rows = [] { const char* e = getenv("RFLU_PANEL_LOCAL_ROWS"); return e ? atoll(e) : (sizeof(T) == 4 ? 8192 : 4096); }();   // (read per launch: tests switch it)
             const bool loc = h->panel_local == 1 || (h->num_cus == 256 && rows <= local_rows && (rows > 512 || tiny_local));
             RFLU_TRY(launch_panel_local<T>(h, p, loc ? 8 : 1, loc ? h->panel_xcc : 0, loc ? h->panel_xcc : -1, loc));
             return RFLU_OK;

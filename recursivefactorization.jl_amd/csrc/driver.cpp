@@ -394,9 +394,10 @@ static int get_pstream(Handle* h, int reserve, hipStream_t* out)
 
 // ---- the schedules' streams on different hardware pipes -------------------------------------------------------------------------
 // Every stream with a CU mask is an HSA queue of its own, and queues are spread round-robin over the 4 pipes of the compute
-// micro-engine in the order the PROCESS created them.  Two busy queues on one pipe cost every kernel of both ~20 us
-// (queue_probe_rate: 5-6 us per back-to-back one-thread kernel on either stream alone or on different pipes, 24-27 us when the two
-// share one; N=4096 12 -> 20 ms, N=16384 82 -> 108 ms when the update or the side stream lands on the critical path's pipe).  Which
+// micro-engine in the order the PROCESS created them.  Two busy queues on one pipe cost every kernel of both ~25 us
+// (queue_probe_rate: two backlogged streams drain their one-thread kernels at 1.7 us per kernel on different pipes, 3.1 us when they are
+// one and the same stream, 28 us when they share a pipe; N=4096 12 -> 20 ms, N=16384 80 -> 108 ms when the update or the side stream
+// lands on the critical path's pipe).  With more than four busy streams somebody has to share; the library uses at most four.  Which
 // queue index a new stream gets depends on how many queues the host program created before -- so it is measured, not assumed: each of
 // the library's masked streams is probed against the caller's stream and the ones already accepted, and replaced by a new one with
 // the same mask (the next queue index) until it shares a pipe with none of them; the rejected streams stay parked, idle.
@@ -416,7 +417,7 @@ static int validate_queues(Handle* h)
     double base = 0;
     RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));
     RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));   // the first pass warms the launch path
-    const double limit = std::max(2.0 * base, base + 5.0);   // measured: 5-7.5 us on different pipes, 19-27 on one
+    const double limit = std::max(2.0 * base, base + 5.0);   // base = the caller's stream against itself (3.1 us); a shared pipe reads 28
     std::vector<hipStream_t> accepted{P};
     const bool verbose = getenv("RFLU_QUEUE_TRACE") != nullptr;
     auto settle = [&](hipStream_t* slot, int r, bool complement) -> int {
@@ -1510,9 +1511,21 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
                 h->bounce[i] = nullptr;
             }
             h->bounce_bytes = 0;
-            for (int i = 0; i < 2; ++i) RFLU_HIP(hipHostMalloc(&h->bounce[i], bounce_bytes));
-            h->bounce_bytes = bounce_bytes;
+            bool ok = true;
+            for (int i = 0; i < 2 && ok; ++i) ok = hipHostMalloc(&h->bounce[i], bounce_bytes) == hipSuccess;
+            if (ok) {
+                h->bounce_bytes = bounce_bytes;
+            } else {   // no pinned memory to be had: the plain sequence (everything after the factorization) needs none
+                (void)hipGetLastError();
+                for (int i = 0; i < 2; ++i) {
+                    if (h->bounce[i]) (void)hipHostFree(h->bounce[i]);
+                    h->bounce[i] = nullptr;
+                }
+                C = nullptr;
+            }
         }
+    }
+    if (early && C) {
         const hipStream_t user = h->stream;
         auto new_event = [h, &ev_used](hipEvent_t* e) -> int {
             if (ev_used == h->out_events.size()) {

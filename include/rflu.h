@@ -61,6 +61,9 @@ enum rflu_kclass {
 /* ---- lifetime ---- */
 int rflu_create(rflu_handle_t* handle, int device);
 int rflu_destroy(rflu_handle_t handle);
+/* The library's RFLU_* tuning / debugging variables (INTEGRATION.md lists them) are read from the environment once, by
+ * rflu_create; this reads them again for an existing handle (a host that changes them between calls: the test-suite). */
+int rflu_reload_tuning(rflu_handle_t handle);
 const char* rflu_last_error(void);
 int rflu_version(void);
 /* Use an existing HIP stream (hipStream_t passed as void*); NULL restores the handle's own stream. */
@@ -196,6 +199,10 @@ int rflu_mgpu_create(rflu_mgpu_t* out, int ndev, const int* devs);
 int rflu_mgpu_destroy(rflu_mgpu_t mgpu);
 int rflu_mgpu_ndev(rflu_mgpu_t mgpu);
 int rflu_mgpu_is_fake(rflu_mgpu_t mgpu);
+/* number of ncclBroadcast calls this object has enqueued so far (0 in fake mode and with one device, unless
+ * RFLU_MGPU_FORCE_RCCL=1 made a one-device object build a one-rank communicator and broadcast to itself: the way the
+ * collective's code path is executed on a box with a single GPU) */
+int64_t rflu_mgpu_collectives(rflu_mgpu_t mgpu);
 /* number of local columns of logical device d for an n-column matrix (-1 on bad arguments) */
 int64_t rflu_mgpu_local_cols(int64_t n, int64_t block, int ndev, int64_t run, int d);
 int rflu_getrf_f64_mgpu(rflu_mgpu_t mgpu, int64_t n, double* const* slabs_dev, const int64_t* lds, int64_t* ipiv_host,

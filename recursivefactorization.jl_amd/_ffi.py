@@ -43,6 +43,7 @@ _TYPED = {
 _PLAIN = {
     "rflu_create": (c_int, [ctypes.POINTER(c_p), c_int]),
     "rflu_destroy": (c_int, [c_p]),
+    "rflu_reload_tuning": (c_int, [c_p]),
     "rflu_last_error": (ctypes.c_char_p, []),
     "rflu_version": (c_int, []),
     "rflu_set_stream": (c_int, [c_p, c_p]),
@@ -55,6 +56,7 @@ _PLAIN = {
     "rflu_mgpu_destroy": (c_int, [c_p]),
     "rflu_mgpu_ndev": (c_int, [c_p]),
     "rflu_mgpu_is_fake": (c_int, [c_p]),
+    "rflu_mgpu_collectives": (c_i64, [c_p]),
     "rflu_mgpu_local_cols": (c_i64, [c_i64, c_i64, c_int, c_i64, c_int]),
     "rflu_getrf_f64_mgpu": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_int, c_i64, c_i64, c_p]),
     "rflu_getrf_f32_mgpu": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_int, c_i64, c_i64, c_p]),
@@ -134,6 +136,10 @@ class Handle:
     def last_path(self) -> int:
         return int(self.lib.rflu_last_path(self.ptr))
 
+    def reload_tuning(self):
+        """Read the RFLU_* tuning variables again (they are read once, when the handle is created)."""
+        check(self.lib.rflu_reload_tuning(self.ptr))
+
     def set_stream(self, stream_ptr: int | None):
         check(self.lib.rflu_set_stream(self.ptr, c_p(stream_ptr or 0)))
 
@@ -168,3 +174,9 @@ def default_handle(device: int = 0) -> Handle:
     if device not in _handles:
         _handles[device] = Handle(device)
     return _handles[device]
+
+
+def reload_tuning() -> None:
+    """Every default handle reads the RFLU_* environment variables again (after a host changed them between calls)."""
+    for h in _handles.values():
+        h.reload_tuning()

@@ -38,13 +38,83 @@ void set_error(const char* fmt, ...)
 
 static int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// ---- the environment, read in ONE place (Tune::load_env / load_handle_env: at rflu_create and on rflu_reload_tuning) -----------
+static const char* env_str(const char* name) { return getenv(name); }
+static void env_get(const char* name, int& v) { if (const char* e = env_str(name)) v = atoi(e); }
+static void env_get(const char* name, int64_t& v) { if (const char* e = env_str(name)) v = atoll(e); }
+static void env_get(const char* name, double& v) { if (const char* e = env_str(name)) v = atof(e); }
+static void env_flag(const char* name, int& v) { if (env_str(name)) v = 1; }   // set = on, whatever the value
+
+void Tune::load_env()
+{
+    *this = Tune();
+    env_get("RFLU_PANEL_PW", panel_pw);
+    env_get("RFLU_PANEL_MAXG", panel_maxg);
+    env_get("RFLU_PANEL_BALLAST", panel_ballast);
+    env_get("RFLU_PANEL_LOCAL_MIN", panel_local_min);
+    env_get("RFLU_PANEL_LOCAL_ROWS", panel_local_rows);
+    env_get("RFLU_PANEL_LOCAL_PW8_ROWS", panel_local_pw8_rows);
+    env_get("RFLU_POLL_DELAY", poll_delay);
+    env_get("RFLU_POLL_ADAPT", poll_adapt);
+    env_get("RFLU_LASWP_LPR", laswp_lpr);
+    env_get("RFLU_GEMM_FLAGS", gemm_flags);
+    env_get("RFLU_SKINNY_MAXK", skinny_max_k);
+    env_get("RFLU_SKINNY_WIDE", skinny_wide);
+    env_get("RFLU_GEMM_CFIRST_BELOW", gemm_cfirst_below);
+    env_get("RFLU_GEMM_MASKED", gemm_masked);
+    env_get("RFLU_LD_PAD", ld_pad);
+    ld_pad = (ld_pad / 16) * 16;
+    env_get("RFLU_TRSV_MAX_RHS", trsv_max_rhs);
+    env_get("RFLU_QUEUE_CHECK", queue_check);
+    env_flag("RFLU_QUEUE_TRACE", queue_trace);
+    env_flag("RFLU_SPLIT_ALL", split_all);
+    env_get("RFLU_SPLIT_SHARE", split_share);
+    env_get("RFLU_SPLIT_SCALE", split_scale);
+    env_get("RFLU_MAX_RESERVE", max_reserve);
+    env_get("RFLU_RESERVE_CUS", min_reserve);
+    env_get("RFLU_CONFINE_ROWS", confine_rows);
+    env_get("RFLU_MERGE_ROWS", merge_rows);
+    env_get("RFLU_LEAFWISE", leafwise);
+    env_get("RFLU_LEAFWISE_ROWS", leafwise_rows);
+    env_get("RFLU_SWAP_SU", swap_su);
+    env_get("RFLU_GATE_FOLD", gate_fold);
+    env_flag("RFLU_GATE_TRACE", gate_trace);
+    if (const char* e = env_str("RFLU_SCHEDULE")) schedule_events = strcmp(e, "events") == 0;
+    env_flag("RFLU_TIME_ENQUEUE", time_enqueue);
+    env_get("RFLU_TAIL_OVERLAP", tail_overlap);
+    env_get("RFLU_HOST_EARLY_OUT", host_early_out);
+    env_flag("RFLU_HOST_TRACE", host_trace);
+    env_get("RFLU_HOST_THREADS", host_threads);
+    env_get("RFLU_MGPU_BIG_RESERVE", mgpu_big_reserve);
+    env_get("RFLU_MGPU_TALL_ROWS", mgpu_tall_rows);
+    env_get("RFLU_MGPU_SYNC", mgpu_sync);
+    env_get("RFLU_DEBUG_GHOST_LEAF", debug_ghost_leaf);
+}
+
+// the handle's own switches (kernel routing) + its Tune
+static void load_handle_env(Handle* h)
+{
+    h->tune.load_env();
+    h->coop_launch = false;
+    h->panel_local = 2;
+    h->panel_single = 1;
+    h->panel_local_maxg = 64;
+    int v = 0;
+    env_get("RFLU_COOP_LAUNCH", v);
+    h->coop_launch = v != 0;
+    env_get("RFLU_PANEL_LOCAL", h->panel_local);
+    env_get("RFLU_PANEL_SINGLE", h->panel_single);
+    if (h->panel_local == 1) h->panel_local_maxg = 32;   // one XCD has 32 CUs
+    env_get("RFLU_PANEL_LOCAL_MAXG", h->panel_local_maxg);
+}
+
 // Leading dimension of the row-major workspace for n columns: a multiple of 16 elements (rows start on 128-byte lines).
 // RFLU_LD_PAD=<elements> adds a padding when that is a multiple of 512 elements (a power-of-two row pitch): measured on MI355X
 // (round 3, N=16384: 82.7 ms / laswp 3.11 TB/s without, 82.3-82.9 ms / 3.0-3.17 TB/s with 16..272 elements) it changes nothing --
 // the HBM address hash already spreads equal columns of consecutive rows over the channels -- so the default is none.
-static int64_t workspace_ld(int64_t n)
+static int64_t workspace_ld(const Handle* h, int64_t n)
 {
-    static const int64_t pad = [] { const char* e = getenv("RFLU_LD_PAD"); return e ? (atoll(e) / 16) * 16 : 0ll; }();
+    const int64_t pad = h->tune.ld_pad;
     int64_t ld = round_up(std::max<int64_t>(n, 1), 16);
     if (pad > 0 && ld % 512 == 0) ld += pad;
     return ld;
@@ -139,7 +209,7 @@ static int getrs_rm(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, 
     // few right-hand sides (<= 32: measured crossover): one cooperative launch per triangle and pass of 8 (trsv.hip)
     // instead of ~n/32 dependent launches; many:
     // the recursive splitting, whose GEMMs then carry the work.  RFLU_TRSV_MAX_RHS moves the crossover (0 = never).
-    static const int64_t trsv_max = [] { const char* e = getenv("RFLU_TRSV_MAX_RHS"); return e ? atoll(e) : 32ll; }();
+    const int64_t trsv_max = h->tune.trsv_max_rhs;
     if (nrhs <= trsv_max && n <= (int64_t)NB * 256 * 4) {
         RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), h->stream));
         RFLU_TRY(launch_trsv_coop<T>(h, n, nrhs, R, ld, B, ldb));
@@ -166,7 +236,7 @@ static int getrs_cm_dev(Handle* h, int64_t n, int64_t nrhs, const T* F, int64_t 
         return RFLU_ERR_ARG;
     }
     if (n == 0 || nrhs == 0) return RFLU_OK;
-    const int64_t ldr = workspace_ld(n), ldx = round_up(nrhs, 16);
+    const int64_t ldr = workspace_ld(h, n), ldx = round_up(nrhs, 16);
     RFLU_TRY(ensure_buffer(&h->work, &h->work_bytes, (size_t)n * (size_t)ldr * sizeof(T)));
     RFLU_TRY(ensure_buffer(&h->rhs_work, &h->rhs_work_bytes, (size_t)n * (size_t)ldx * sizeof(T)));
     T* R = static_cast<T*>(h->work);
@@ -234,10 +304,9 @@ template <typename T>
 static int gemm_public(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B, int64_t ldb, T* C,
                        int64_t ldc)
 {
-    const char* e = getenv("RFLU_GEMM_MASKED");
-    if (e == nullptr) return launch_gemm<T>(h, M, N, K, A, lda, B, ldb, C, ldc);
+    if (h->tune.gemm_masked < 0) return launch_gemm<T>(h, M, N, K, A, lda, B, ldb, C, ldc);
     hipStream_t U, saved = h->stream;
-    RFLU_TRY(get_ustream(h, atoi(e), &U));
+    RFLU_TRY(get_ustream(h, h->tune.gemm_masked, &U));
     RFLU_HIP(hipStreamSynchronize(saved));
     h->stream = U;
     const int rc = launch_gemm<T>(h, M, N, K, A, lda, B, ldb, C, ldc);
@@ -279,34 +348,12 @@ struct Fact {
         return RFLU_OK;
     }
 
-    // two full leaves in one cooperative launch (panel.hip: panel_pivot_pair_kernel) + one interchange launch: both
-    // leaves' interchanges on the columns outside the pair, leaf B's on leaf A's columns, both diagonal inverses
-    int leaf_pair(int64_t c0)
-    {
-        const int64_t r0 = c0 + roff;
-        RFLU_TRY(launch_panel_pair<T>(h, R, ld, m, r0, c0, ipiv));
-        const int64_t hi = sw_hi < 0 ? n : sw_hi;
-        return launch_laswp3<T>(h, R, ld, sw_lo, c0 - sw_lo, c0 + 2 * NB, hi - (c0 + 2 * NB), c0, NB, r0 / NB, r0 / NB + 2,
-                                NB, 2, R + r0 * ld + c0, linv_at(r0));
-    }
-
-    bool pair_ok(int64_t c0) const
-    {
-        // opt-in (RFLU_PAIR=1): correct and parity-tested, but at its current inter-leaf cost (~100 us: slot gather 25,
-        // LDS solve 24, LDS-bandwidth-bound Schur update 40) it is 6 % slower than the three launches it replaces
-        const char* e = getenv("RFLU_PAIR");
-        const bool on = e != nullptr && e[0] == '1';
-        const int64_t rows = m - (c0 + roff);
-        return pivot && on && rows >= 2 * NB && (rows + PANEL_THREADS - 1) / PANEL_THREADS <= MAX_PANEL_WGS;
-    }
-
     // reckernel! (src/lu.jl:189-263) on columns [c0, c1), rows [c0+roff, m)
     int rec(int64_t c0, int64_t c1)
     {
         const int64_t w = c1 - c0;
         if (w <= 0) return RFLU_OK;
         if (w <= NB) return leaf(c0, w);
-        if (w == 2 * NB && pair_ok(c0)) return leaf_pair(c0);
         const int64_t leaves = (w + NB - 1) / NB;
         const int64_t n1 = ((leaves + 1) / 2) * NB;
         const int64_t cm = c0 + n1;
@@ -404,8 +451,7 @@ static int get_pstream(Handle* h, int reserve, hipStream_t* out)
 // Re-checked when the caller's stream changes (rflu_set_stream) or a new masked stream appears.  RFLU_QUEUE_CHECK=0 skips it.
 static int validate_queues(Handle* h)
 {
-    static const bool off = [] { const char* e = getenv("RFLU_QUEUE_CHECK"); return e && atoi(e) == 0; }();
-    if (off) return RFLU_OK;
+    if (!h->tune.queue_check) return RFLU_OK;
     int created = 0;
     for (int r = 1; r < 8; ++r) created += (h->ustreams[r] != nullptr) + (h->pstreams[r] != nullptr);
     if (h->queues_ok_count != created) h->queues_ok_streams.clear();
@@ -419,7 +465,7 @@ static int validate_queues(Handle* h)
     RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));   // the first pass warms the launch path
     const double limit = std::max(2.0 * base, base + 5.0);   // base = the caller's stream against itself (3.1 us); a shared pipe reads 28
     std::vector<hipStream_t> accepted{P};
-    const bool verbose = getenv("RFLU_QUEUE_TRACE") != nullptr;
+    const bool verbose = h->tune.queue_trace != 0;
     auto settle = [&](hipStream_t* slot, int r, bool complement) -> int {
         for (int attempt = 0; attempt < 8; ++attempt) {
             double worst = 0;
@@ -485,20 +531,13 @@ template <typename T>
 static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U_last)
 {
     Handle* h = f.h;
-    int min_reserve = 32;
-    double split_scale = 1.0;
-    const bool split_all = getenv("RFLU_SPLIT_ALL") != nullptr;
-    double split_share = 0.5;   // tuning knob: how much of what is left after the modelled time stays on the update stream
-    if (const char* e = getenv("RFLU_SPLIT_SHARE")) split_share = atof(e);
-    int max_reserve = 64;       // taller panels (> 64 workgroups) take too many CUs from the update: one stream instead
-    if (const char* e = getenv("RFLU_MAX_RESERVE")) max_reserve = atoi(e);
-    if (const char* e = getenv("RFLU_RESERVE_CUS")) {  // tuning knob: least number of CUs kept away from the update stream
-        const int v = atoi(e);
-        if (v >= 32 && v <= 224 && v % 32 == 0) min_reserve = v;
-    }
-    if (const char* e = getenv("RFLU_SPLIT_SCALE")) {  // tuning knob: scales the modelled critical-path time (0 = no split)
-        split_scale = atof(e);
-    }
+    // tuning knobs (Tune): split_share = how much of what is left after the modelled time stays on the update stream;
+    // max_reserve: taller panels (> 64 workgroups) take too many CUs from the update: one stream instead; min_reserve: least number
+    // of CUs kept away from the update stream; split_scale scales the modelled critical-path time (0 = no split)
+    const int min_reserve = (h->tune.min_reserve >= 32 && h->tune.min_reserve <= 224 && h->tune.min_reserve % 32 == 0) ? h->tune.min_reserve : 32;
+    const double split_scale = h->tune.split_scale, split_share = h->tune.split_share;
+    const bool split_all = h->tune.split_all != 0;
+    const int max_reserve = h->tune.max_reserve;
     hipStream_t P = h->stream;
     const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
     T* R = f.R;
@@ -511,8 +550,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     // Confining the critical path to the reserved CUs while the update is the bottleneck: round 2 measured +1.3 ms in its favour,
     // round 3 -2.4 ms against it with all four streams on pipes of their own (validate_queues; without that a fourth stream may share
     // a pipe with one of the other three, which costs 25-60 %): off unless RFLU_CONFINE_ROWS asks for it.
-    int64_t confine_rows = (int64_t)1 << 40;
-    if (const char* e = getenv("RFLU_CONFINE_ROWS")) confine_rows = atoll(e);
+    const int64_t confine_rows = h->tune.confine_rows;
     auto move_P = [&](hipStream_t to, int64_t b) -> int {
         if (to == P) return RFLU_OK;
         hipEvent_t e0;
@@ -545,10 +583,8 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     // solves and a 496-tile GEMM that fills 1.1 rounds of the 448 workgroup slots: ~450 us per block column at N=16384) but as the
     // FIRST tile columns of the one bulk update; the GEMM publishes a gate when those tiles are done and the critical path waits
     // on that gate instead of an event.
-    int64_t merge_rows = sizeof(T) == 8 ? 8192 : (int64_t)1 << 40;
-    if (const char* e = getenv("RFLU_MERGE_ROWS")) merge_rows = atoll(e);
-    if (const char* cc = getenv("ROCPROF_COUNTER_COLLECTION"); cc && atoi(cc) != 0)
-        merge_rows = (int64_t)1 << 40;   // kernels run one at a time under counter collection: no device-side gates (see getrf_rm)
+    int64_t merge_rows = h->tune.merge_rows >= 0 ? h->tune.merge_rows : (sizeof(T) == 8 ? 8192 : (int64_t)1 << 40);
+    if (h->tune.schedule_events) merge_rows = (int64_t)1 << 40;   // RFLU_SCHEDULE=events: no device-side gates (see getrf_rm)
     {   // the gate needs P and U to run concurrently: only with a real CU-masked update stream (create it now to find out)
         hipStream_t probe;
         RFLU_TRY(get_ustream(h, 32, &probe));
@@ -765,11 +801,9 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     // leaf needs the side stream (2.4 ms stall), and moving that update to the 192-CU stream costs what the swap wins (N=16384
     // 85.1 vs 85.3 ms, N=12288 49.0 vs 48.8): there the update keeps 224 CUs and the side stream takes the 192-CU stream.
     // (Float32 at N=16384 is leaf-wise from block column 0 as well, but there the update still needs its 224 CUs: 63.9 vs 62.1 ms.)
-    bool swap_su = b_begin == 0 && m <= 8192;
-    if (const char* e = getenv("RFLU_SWAP_SU")) swap_su = atoi(e) != 0;
-    const bool fold = !(getenv("RFLU_GATE_FOLD") && atoi(getenv("RFLU_GATE_FOLD")) == 0) && !getenv("RFLU_GATE_TRACE");
-    int64_t confine_rows = (int64_t)1 << 40;
-    if (const char* e = getenv("RFLU_CONFINE_ROWS")) confine_rows = atoll(e);
+    const bool swap_su = h->tune.swap_su >= 0 ? h->tune.swap_su != 0 : (b_begin == 0 && m <= 8192);
+    const bool fold = h->tune.gate_fold != 0 && !h->tune.gate_trace;
+    const int64_t confine_rows = h->tune.confine_rows;
     auto reserve_for = [&](int64_t rows) {
         const int64_t g = panel_wgs(h, rows, f.pivot);
         return std::max<int>(32, int((g + 31) / 32 * 32));
@@ -817,7 +851,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     h->gate_epoch += (unsigned long long)nleaf + 2;
     auto val = [&](int64_t g) { return gbase + (unsigned long long)g + 1; };
     const int64_t gfirst = b_begin * W / NB;   // the leaves before it were factored (and applied everywhere) by factor_lookahead
-    if (getenv("RFLU_GATE_TRACE") && !h->gate_stamps) {
+    if (h->tune.gate_trace && !h->gate_stamps) {
         RFLU_HIP(hipMalloc((void**)&h->gate_stamps, 3 * 4096 * sizeof(long long)));
         RFLU_HIP(hipMemset(h->gate_stamps, 0, 3 * 4096 * sizeof(long long)));
     }
@@ -929,340 +963,6 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     return RFLU_OK;
 }
 
-// Deep-lookahead schedule (round 3): the pivot chain and the bulk update overlap from the first block column to the last.
-//
-// factor_lookahead / factor_leafwise keep the update stream right-looking and in order: block column b+1 becomes current only
-// when U has applied block column b to EVERYTHING, so a factorization runs as an update-bound half (the chain waits) followed
-// by a chain-bound half (the update stream idles); floor ~72 ms at N=16384 with both resources at ~52-55 ms.  Here U keeps,
-// per column block c, a[c] = "block columns [0, a[c]) have been applied" and s[c] = "the interchanges of block columns
-// [0, s[c]) have been applied" (s >= a), and works in SWEEPS: after block column b is factored it brings the columns right of
-// the window up to date left to right -- nearest (= needed soonest) first -- and stops where a cost model says the next block
-// column will be finished; what it did not reach stays behind and is picked up by later sweeps, several block columns at a
-// time as ONE update with K = (number of pending block columns) * W (fewer passes over C, better MFMA rate).
-// Interchanges: at the start of sweep(b) every finished L column takes block column b's interchanges (as in the round-2
-// schedules), so all of L is always in the CURRENT row order; a lagging column group first receives the interchanges it has
-// missed and is then updated against L in that same row order.  P (A - L U) = P A - (P L) U: permuting the rows below a block row
-// consistently on both sides commutes with that block row's elimination, so every entry still receives the eliminations of
-// src/lu.jl:229-246 in the same order -- only WHEN a far column receives them changes, and how many share one K loop.
-//   P (caller's stream)  : the chain.  Tall panels (> lw_rows rows): Toledo recursion on the block column, then the update of
-//                          block column b+1.  Short panels: leaf by leaf as in factor_leafwise.
-//   S (side stream)      : tall panels: block column b applied to the WINDOW [b+2, b+1+dwin] right after it is factored (the
-//                          window is what lets U be late without the chain noticing: only the column block that ENTERS the window
-//                          comes from U, and it is the last thing S touches); short panels: the per-leaf updates of
-//                          factor_leafwise (rest of the block column, next block column).
-//   U (update stream)    : the sweeps and the interchanges on finished L columns.
-// Three queues in all (DESIGN.md "queues").  Cross-stream edges once per block column: hipEvents, and one device-side gate where
-// the waiter is the chain itself.
-template <typename T>
-static int factor_deep(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U_before, int64_t lw_rows)
-{
-    Handle* h = f.h;
-    const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
-    T* R = f.R;
-    const hipStream_t userS = h->stream;
-    struct Restore { Handle* h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, userS};
-    const hipStream_t P = userS;
-    const int64_t nblk = (mn + W - 1) / W, nleaf = (mn + NB - 1) / NB, ncb = (n + W - 1) / W;
-    auto evS = [](int64_t b) { return 4 * (size_t)b + 0; };
-    auto evP = [](int64_t b) { return 4 * (size_t)b + 1; };
-    auto evU1 = [](int64_t b) { return 4 * (size_t)b + 2; };
-    auto evUend = [](int64_t b) { return 4 * (size_t)b + 3; };
-    bool swap_su = b_begin == 0 && m <= 8192;   // see factor_leafwise
-    if (const char* e = getenv("RFLU_SWAP_SU")) swap_su = atoi(e) != 0;
-    const bool fold = !(getenv("RFLU_GATE_FOLD") && atoi(getenv("RFLU_GATE_FOLD")) == 0) && !getenv("RFLU_GATE_TRACE");
-    int64_t dwin = 3;
-    if (const char* e = getenv("RFLU_DEEP_WIN")) dwin = std::max<int64_t>(1, atoll(e));
-    double scale_rec = 1.3, scale_leaf = 1.3;    // share of a block column's time a sweep may fill: the side stream's updates share
-                                                 // the CUs, and in the leaf-wise part nothing absorbs a sweep that runs long
-    if (const char* e = getenv("RFLU_DEEP_SCALE")) scale_rec = atof(e);
-    if (const char* e = getenv("RFLU_DEEP_SCALE_LEAF")) scale_leaf = atof(e);
-    int64_t kmax = 1;            // at most this many pending block columns share one update (K = kmax * W)
-    if (const char* e = getenv("RFLU_DEEP_KMAX")) kmax = std::max<int64_t>(1, atoll(e));
-    int64_t Q = 8;               // a sweep cuts a column group only at multiples of Q column blocks (no slivers)
-    if (const char* e = getenv("RFLU_DEEP_Q")) Q = std::max<int64_t>(1, atoll(e));
-    const bool trace = getenv("RFLU_DEEP_TRACE") != nullptr;
-    auto wait_on = [&](hipStream_t st, size_t idx) -> int {
-        hipEvent_t e;
-        RFLU_TRY(get_event(h, idx, &e));
-        RFLU_HIP(hipStreamWaitEvent(st, e, 0));
-        return RFLU_OK;
-    };
-    auto record_on = [&](hipStream_t st, size_t idx) -> int {
-        hipEvent_t e;
-        RFLU_TRY(get_event(h, idx, &e));
-        RFLU_HIP(hipEventRecord(e, st));
-        return RFLU_OK;
-    };
-    hipStream_t S, U;
-    RFLU_TRY(get_ustream(h, swap_su ? 32 : 64, &S));
-    RFLU_TRY(get_ustream(h, swap_su ? 64 : 32, &U));
-    if (b_begin > 0) {   // everything right of block column b_begin was last written by factor_lookahead's update stream
-        if (U_before && U_before != U) RFLU_TRY(wait_on(U, evUend(b_begin - 1)));
-        if (U_before && U_before != S) RFLU_TRY(wait_on(S, evUend(b_begin - 1)));
-    }
-    if (f.tail) {   // column-major entry: the layout change of the columns right of the first block column is still in flight
-        RFLU_HIP(hipStreamWaitEvent(S, f.tail, 0));
-        RFLU_HIP(hipStreamWaitEvent(U, f.tail, 0));
-    }
-    auto chunk_of = [&](int64_t blk) { return (std::min(blk * W, mn) + NB - 1) / NB; };   // first pivot chunk of block column blk
-    // leaf (columns c0..c0+w) applied to columns [a, b): interchanges (optional), block-row solve, Schur update (K = w)
-    auto apply_leaf = [&](hipStream_t st, int64_t c0, int64_t w, int64_t a, int64_t b, bool swaps) -> int {
-        if (b <= a) return RFLU_OK;
-        hipStream_t saved = h->stream;
-        h->stream = st;
-        int rc = RFLU_OK;
-        if (swaps && f.pivot) rc = launch_laswp<T>(h, R, ld, a, b - a, c0 / NB, c0 / NB + 1);
-        if (rc == RFLU_OK) rc = launch_trsm_inv64<T>(h, w, b - a, f.linv_at(c0), R + c0 * ld + a, ld);
-        if (rc == RFLU_OK && m > c0 + w)
-            rc = launch_gemm<T>(h, m - c0 - w, b - a, w, R + (c0 + w) * ld + c0, ld, R + c0 * ld + a, ld, R + (c0 + w) * ld + a, ld);
-        h->stream = saved;
-        return rc;
-    };
-    // columns [c0, c1): the interchanges of block columns [s0, s1), then block columns [ja, jz) as ONE update:
-    // block-row solve against the (jz - ja) W triangle, Schur update with K = (jz - ja) W
-    auto advance = [&](hipStream_t st, int64_t s0, int64_t s1, int64_t ja, int64_t jz, int64_t c0, int64_t c1,
-                       LaswpGate gate = LaswpGate{}) -> int {
-        if (c1 <= c0) return RFLU_OK;
-        const int64_t r0 = ja * W, r1 = std::min(jz * W, mn), k = r1 - r0;
-        hipStream_t saved = h->stream;
-        h->stream = st;
-        int rc = RFLU_OK;
-        if (f.pivot && s1 > s0) rc = launch_laswp2<T>(h, R, ld, c0, c1 - c0, 0, 0, chunk_of(s0), chunk_of(s1), 0, nullptr, nullptr, gate);
-        else if (gate.wait_flag) rc = launch_gate_wait(h, gate.wait_flag, gate.wait_val);
-        if (rc == RFLU_OK && k > 0) rc = trsm_rec<T>(h, k, c1 - c0, R + r0 * ld + r0, ld, R + r0 * ld + c0, ld, f.linv_at(r0));
-        if (rc == RFLU_OK && k > 0 && m > r1)
-            rc = launch_gemm<T>(h, m - r1, c1 - c0, k, R + r1 * ld + r0, ld, R + r0 * ld + c0, ld, R + r1 * ld + c0, ld);
-        h->stream = saved;
-        return rc;
-    };
-    // ---- cost model (microseconds): what the chain needs for a block column, what an update costs on the masked stream ----
-    auto is_leaf_mode = [&](int64_t b) { return m - b * W <= lw_rows; };
-    auto chain_us = [&](int64_t b) -> double {   // from "block column b-1 factored" to "block column b factored"
-        if (b >= nblk) return 0.0;
-        const int64_t j0 = b * W, jb = std::min(W, mn - j0), rows = m - j0;
-        const double G = double((rows + PANEL_THREADS - 1) / PANEL_THREADS);
-        if (is_leaf_mode(b)) return double((jb + NB - 1) / NB) * (NB * (2.6 + 0.025 * G) + 45.0);
-        return model_panel_us(rows, jb) + 120.0 + 2.0 * double(rows) * double(jb) * double(W) / model_gemm_flops_per_us(W, 256, sizeof(T));
-    };
-    auto task_us = [&](int64_t ja, int64_t jz, int64_t ncols) -> double {
-        const int64_t r0 = ja * W, r1 = std::min(jz * W, mn), k = r1 - r0;
-        double t = 40.0 + 15.0 * double(k) / 128.0                          // launches: interchanges, solve strips / merges, update
-                   + double(k) * double(k) * double(ncols) / 25e6;            // the triangle's own flops (small-K GEMMs + strips)
-        if (m > r1) t += 2.0 * double(m - r1) * double(ncols) * double(k) / model_gemm_flops_per_us(k, 224, sizeof(T));
-        return t;
-    };
-    auto swap_us = [&](int64_t s0, int64_t s1, int64_t ncols) -> double {
-        return s1 > s0 && f.pivot ? 10.0 + 4.0 * sizeof(T) * double(ncols) * double((s1 - s0) * W) / 2.4e6 : 0.0;
-    };
-    std::vector<int64_t> a((size_t)ncb + 1, b_begin);    // a[c]: block columns [0, a[c]) have been applied to column block c
-    std::vector<int64_t> sw((size_t)ncb + 1, b_begin);   // sw[c]: ... and the interchanges of block columns [0, sw[c])
-    double tU = 0.0, tE = 0.0;   // model clocks: the update stream; the chain at "block column b factored"
-    // Sweep after block column b: columns [rs, ncb) towards a = b + 1, nearest first.  Column block rs is REQUIRED (the window /
-    // the next block column takes it over next).  Beyond it: run by run (equally old neighbours); a run that is one block column
-    // behind is cut by columns when the budget ends (at a multiple of Q column blocks), an older run is advanced over its whole
-    // width by as many block columns as fit (<= kmax per update).  all = no budget: bring everything up to date.
-    auto sweep = [&](int64_t b, int64_t rs, double budget, bool all) -> int {
-        const int64_t target = b + 1;
-        double used = 0.0;
-        auto run = [&](int64_t jz, int64_t c, int64_t c2) -> int {   // column blocks [c, c2): interchanges up to date, a -> jz
-            const int64_t x0 = c * W, x1 = std::min(c2 * W, n);
-            const int64_t ja = a[c], s0 = sw[c];
-            RFLU_TRY(advance(U, s0, target, ja, jz, x0, x1));
-            const double t = task_us(ja, jz, x1 - x0) + swap_us(s0, target, x1 - x0);
-            used += t;
-            if (trace) fprintf(stderr, "[deep] sweep %lld: block columns %lld..%lld -> column blocks %lld..%lld (%.0f us; used %.0f of %.0f)\n",
-                               (long long)b, (long long)ja, (long long)jz - 1, (long long)c, (long long)c2 - 1, t, used, budget);
-            for (int64_t cc = c; cc < c2; ++cc) { a[cc] = jz; sw[cc] = target; }
-            return RFLU_OK;
-        };
-        auto run_end = [&](int64_t c) { int64_t c2 = c + 1; while (c2 < ncb && a[c2] == a[c] && sw[c2] == sw[c]) ++c2; return c2; };
-        if (rs < ncb && a[rs] < target) {   // the required column block: with its whole run if that fits, alone otherwise
-            int64_t c2 = run_end(rs);
-            double full = 0.0;
-            for (int64_t j = a[rs]; j < target; j += kmax) full += task_us(j, std::min(j + kmax, target), std::min(c2 * W, n) - rs * W);
-            if (!all && full > budget * 1.15) {
-                const int64_t fit = (int64_t)(double(c2 - rs) * budget / full / double(Q) + 0.5) * Q;
-                c2 = rs + std::max<int64_t>(1, std::min(fit, c2 - rs));
-            }
-            while (a[rs] < target) RFLU_TRY(run(std::min(a[rs] + kmax, target), rs, c2));
-        }
-        RFLU_TRY(record_on(U, evU1(b)));
-        for (int64_t c = rs; c < ncb;) {
-            if (a[c] >= target) { ++c; continue; }
-            const int64_t c2 = run_end(c);
-            const int64_t ncols = std::min(c2 * W, n) - c * W;
-            bool stop = false;
-            while (a[c] < target && !stop) {
-                int64_t kk = std::min(kmax, target - a[c]);
-                const double sus = swap_us(sw[c], target, ncols);
-                while (!all && kk >= 1 && used + sus + task_us(a[c], a[c] + kk, ncols) > budget * 1.1) --kk;
-                if (kk >= 1) {
-                    RFLU_TRY(run(a[c] + kk, c, c2));
-                    continue;
-                }
-                // not even one block column over the whole run: what fits of it, by columns (whole multiples of Q column blocks)
-                const double t1 = task_us(a[c], a[c] + 1, ncols) + sus;
-                const int64_t fit = (int64_t)(double(c2 - c) * (budget - used) / t1 / double(Q) + 0.5) * Q;
-                if (fit >= Q && fit < c2 - c) RFLU_TRY(run(a[c] + 1, c, c + fit));
-                else if (fit >= c2 - c) RFLU_TRY(run(a[c] + 1, c, c2));
-                stop = true;
-            }
-            if (stop) break;
-            c = c2;
-        }
-        tU += used;
-        return RFLU_OK;
-    };
-    const unsigned long long gbase = h->gate_epoch;
-    h->gate_epoch += (unsigned long long)nleaf + 2;
-    const unsigned long long wbase = h->gate_epoch;
-    h->gate_epoch += (unsigned long long)nblk + 2;
-    auto val = [&](int64_t g) { return gbase + (unsigned long long)g + 1; };
-    auto wval = [&](int64_t b) { return wbase + (unsigned long long)b + 1; };
-    int64_t gfirst = -1;        // first leaf factored leaf-wise (the gates of earlier leaves are never published)
-    bool prev_rec = false;      // the previous block column was factored by the recursion (its window belongs to S)
-    for (int64_t b = b_begin; b < nblk; ++b) {
-        const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
-        const int64_t bend = std::min(j0 + W, n), wend = std::min(j0 + 2 * W, n);
-        const bool leaf_mode = is_leaf_mode(b);
-        const int64_t g0 = j0 / NB, nl = (jb + NB - 1) / NB, glast = g0 + nl - 1;
-        h->stream = P;
-        if (!leaf_mode) {
-            // ---- chain: Toledo recursion on the block column, interchanges confined to its own columns ----
-            f.sw_lo = j0;
-            f.sw_hi = je;
-            RFLU_TRY(f.rec(j0, je));
-            f.sw_lo = 0;
-            f.sw_hi = -1;
-            if (b == 0 && f.tail) {
-                RFLU_HIP(hipStreamWaitEvent(P, f.tail, 0));
-                f.tail = nullptr;
-            }
-            RFLU_TRY(record_on(P, evP(b)));
-            // ---- chain: block column b+1 (its earlier updates came from the window stream, or from U when it entered there) ----
-            if (je < n) {
-                LaswpGate pgate;
-                if (b > b_begin && prev_rec) {
-                    pgate.wait_flag = h->gates + 3;
-                    pgate.wait_val = wval(b - 1);
-                    pgate.info = h->info_dev;
-                } else if (b > 0) {
-                    RFLU_TRY(wait_on(P, evU1(b - 1)));
-                }
-                RFLU_TRY(advance(P, b, b + 1, b, b + 1, je, std::min(je + W, n), pgate));
-                if (b + 1 < ncb) a[b + 1] = sw[b + 1] = b + 1;
-            }
-            // ---- window stream: block column b on [b+2, b+1+dwin]; the column block that ENTERS the window comes from U and is
-            // touched last, so a late sweep holds up nothing the chain needs soon ----
-            const int64_t w0 = b + 2, w1 = std::min(b + 2 + dwin, ncb);
-            RFLU_TRY(wait_on(S, evP(b)));
-            const bool entering = b > b_begin && w1 > w0 && w1 - 1 == b + 1 + dwin;
-            const int64_t wmid = entering ? w1 - 1 : w1;
-            auto publish = [&]() -> int {   // block column b+2 is ready for the chain
-                h->stream = S;
-                const int rc = launch_gate_signal(h, h->gates + 3, wval(b));
-                h->stream = P;
-                return rc;
-            };
-            if (wmid > w0) {
-                RFLU_TRY(advance(S, b, b + 1, b, b + 1, w0 * W, std::min(wmid * W, n)));
-                RFLU_TRY(publish());
-            }
-            if (entering) {
-                RFLU_TRY(wait_on(S, evU1(b - 1)));   // U's required update of the previous sweep
-                RFLU_TRY(advance(S, b, b + 1, b, b + 1, wmid * W, std::min(w1 * W, n)));
-            }
-            if (wmid <= w0) RFLU_TRY(publish());
-            for (int64_t c = w0; c < w1; ++c) a[c] = sw[c] = b + 1;
-            RFLU_TRY(record_on(S, evS(b)));
-        } else {
-            // ---- chain: leaf by leaf (factor_leafwise) ----
-            if (gfirst < 0) gfirst = g0;
-            if (b == 0 && f.tail) {
-                RFLU_HIP(hipStreamWaitEvent(P, f.tail, 0));
-                f.tail = nullptr;
-            }
-            for (int64_t i = 0; i < nl; ++i) {
-                const int64_t g = g0 + i, c0 = j0 + i * NB, w = std::min<int64_t>(NB, je - c0);
-                RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, f.ipiv, f.pivot));
-                const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);
-                const unsigned long long* wflag = nullptr;   // leaf g-1 reached LA through the side stream: its own block's part, or the next block's
-                if (la1 > la0 && g > gfirst) wflag = h->gate_ptr[la0 < std::min(((c0 - NB) / W + 1) * W, n) ? 1 : 2];
-                if (f.pivot && fold) {
-                    LaswpGate gt;
-                    gt.wait_flag = wflag;
-                    gt.wait_val = wflag ? val(g - 1) : 0;
-                    gt.signal_flag = h->gate_ptr[0];
-                    gt.signal_val = val(g);
-                    gt.signal_cnt = reinterpret_cast<unsigned*>(h->gates + 4);
-                    gt.info = h->info_dev;
-                    RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0), gt));
-                } else {
-                    if (wflag) RFLU_TRY(launch_gate_wait(h, wflag, val(g - 1)));
-                    if (f.pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0)));
-                    RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g)));
-                }
-                RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
-                // ---- side stream: leaf g on the rest of this block column and on the next one ----
-                h->stream = S;
-                int rc = launch_gate_wait(h, h->gate_ptr[0], val(g));
-                if (i == 0 && b > 0 && !(b > b_begin && prev_rec)) {
-                    // the next block column holds the earlier block columns' updates only after U's required update of the last
-                    // sweep; the chain needs this block column's part first: two pieces with a gate of its own in between
-                    if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, la1, bend, true);
-                    h->stream = S;
-                    if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g));
-                    if (rc == RFLU_OK) rc = wait_on(S, evU1(b - 1));
-                    if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, std::max(la1, bend), wend, true);
-                    h->stream = S;
-                    if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[2], val(g));
-                } else {
-                    if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, la1, wend, true);
-                    h->stream = S;
-                    if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g));
-                    if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[2], val(g));
-                }
-                h->stream = P;
-                RFLU_TRY(rc);
-            }
-            if (b + 1 < ncb) a[b + 1] = sw[b + 1] = b + 1;
-            RFLU_TRY(record_on(S, evS(b)));
-            // U goes on when the side stream has applied the last leaf
-            h->stream = U;
-            const int rcw = launch_gate_wait(h, h->gate_ptr[2], val(glast));
-            h->stream = P;
-            RFLU_TRY(rcw);
-        }
-        // ---- U: sweep(b).  First the interchanges of block column b on everything finished (all of L stays in the current row
-        // order); the side stream's last reads of L in the previous order must be over (its window update of block column b-1)
-        if (!leaf_mode) RFLU_TRY(wait_on(U, evP(b)));
-        if (b > b_begin && prev_rec) RFLU_TRY(wait_on(U, evS(b - 1)));
-        if (f.pivot) {
-            hipStream_t saved = h->stream;
-            h->stream = U;
-            int rc = RFLU_OK;
-            if (leaf_mode)
-                for (int64_t i = 0; i + 1 < nl && rc == RFLU_OK; ++i)   // leaf i's columns: the later leaves' interchanges
-                    rc = launch_laswp<T>(h, R, ld, j0 + i * NB, NB, g0 + i + 1, g0 + nl);
-            if (rc == RFLU_OK && j0 > 0) rc = launch_laswp<T>(h, R, ld, 0, j0, g0, g0 + nl);
-            h->stream = saved;
-            RFLU_TRY(rc);
-        }
-        const double period = chain_us(b + 1);
-        tE += chain_us(b);
-        tU = std::max(tU, tE);
-        const bool last = b + 1 >= nblk;
-        const bool next_leaf = b + 1 < nblk && is_leaf_mode(b + 1);
-        const int64_t rs = b + 2 + (leaf_mode ? 0 : dwin);
-        RFLU_TRY(sweep(b, rs, (next_leaf ? scale_leaf : scale_rec) * (tE + period - tU), last));
-        RFLU_TRY(record_on(U, evUend(b)));
-        prev_rec = !leaf_mode;
-    }
-    h->stream = P;
-    RFLU_TRY(wait_on(P, evUend(nblk - 1)));
-    RFLU_TRY(wait_on(P, evS(nblk - 1)));
-    return RFLU_OK;
-}
 
 // Factor the row-major m x n matrix R in place (see rflu.h for `blocksize`).
 template <typename T>
@@ -1282,6 +982,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     h->last_path = RFLU_PATH_NONE;
     if (mn == 0) return RFLU_OK;
     RFLU_TRY(ensure_bookkeeping(h, m));
+    h->coop_leaf_seq = 0;
     RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), h->stream));
     // the wrapping "last workgroup" counters of the folded gates: a factorization that timed out or was aborted may have left
     // them mid-count, and a stale count would publish the next factorization's gate early or never
@@ -1307,17 +1008,12 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
         h->last_path = RFLU_PATH_HIP_LOOKAHEAD;
         // tall block columns (update-bound): factor_lookahead; from the first panel of at most lw_rows rows on: factor_leafwise.
         // RFLU_LEAFWISE=0 keeps the lookahead schedule to the end.
-        const char* lw = getenv("RFLU_LEAFWISE");
-        int leafwise = lw ? atoi(lw) : 1;
+        int leafwise = h->tune.leafwise;
         // rocprofv3 --pmc runs ONE kernel at a time across all queues: a gate kernel waiting for another stream's kernel would
-        // never see it start (the 2 s gate timeout turns that into RFLU_ERR_TIMEOUT).  Counter collection therefore gets the
-        // lookahead schedule, whose cross-stream edges are hipEvents, to the end.
-        if (const char* cc = getenv("ROCPROF_COUNTER_COLLECTION"); cc && atoi(cc) != 0 && !lw) {
-            static bool told = false;
-            if (!told) fprintf(stderr, "[rflu] counter collection serialises kernels: leaf-wise schedule off for this process\n");
-            told = true;
-            leafwise = 0;
-        }
+        // never see it start (the 2 s gate timeout turns that into RFLU_ERR_TIMEOUT).  A counter-collection run therefore asks
+        // for RFLU_SCHEDULE=events: the lookahead schedule, whose cross-stream edges are hipEvents, to the end (same kernels on
+        // the same shapes for the bulk of the work; scripts/collect_profiles.sh sets it for the --pmc passes only).
+        if (h->tune.schedule_events) leafwise = 0;
         {   // the leaf-wise / deep schedules hand work between streams through device-side gates: only with real CU-masked streams
             hipStream_t probe;
             RFLU_TRY(get_ustream(h, 32, &probe));
@@ -1335,26 +1031,12 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             // Float64: panels at most this tall are the bottleneck of their block column (N=16384: 84.8 ms at 7168-8192, 85.4 at
             // 9216, 88.3 for the whole matrix); Float32's faster GEMM leaves the panel the bottleneck everywhere (61.7 vs 64.5 ms)
             int64_t lw_rows = sizeof(T) == 8 ? 8192 : 16384;   // 16384 rows = 32 workgroups: the most the 32 reserved CUs take
-            if (const char* e = getenv("RFLU_LEAFWISE_ROWS")) lw_rows = atoll(e);
+            if (h->tune.leafwise_rows >= 0) lw_rows = h->tune.leafwise_rows;
             lw_rows = std::min<int64_t>(lw_rows, 32 * (int64_t)PANEL_THREADS);
             b_switch = m <= lw_rows ? 0 : std::min(nblk, (m - lw_rows + Wb - 1) / Wb);
         }
         hipStream_t U_last = nullptr;
-        // Deep lookahead (factor_deep, RFLU_DEEP=1) wherever the panel fits the 32 reserved CUs (<= 16384 rows) and the block
-        // columns are leaf-wise capable; taller block columns keep factor_lookahead.  Opt-in: measured (round 3, N=16384 Float64)
-        // 82.7-84 ms against 83.6 ms for the round-2 pair of schedules -- the update side (GEMM at its in-schedule rate plus its
-        // interchanges / solves / the leaf-wise K=64 updates) is ~80 ms of work on the masked CUs however it is ordered, so
-        // overlapping it better with the pivot chain buys nothing until that work gets cheaper.
-        const bool deep_on = [] { const char* e = getenv("RFLU_DEEP"); return e != nullptr && atoi(e) != 0; }();
-        if (deep_on && leafwise && Wb >= 2 * NB && Wb <= 512) {
-            const int64_t deep_rows = 32 * (int64_t)PANEL_THREADS;
-            const int64_t b_deep = m <= deep_rows ? 0 : std::min(nblk, (m - deep_rows + Wb - 1) / Wb);
-            int64_t lw_rows = sizeof(T) == 8 ? 8192 : 16384;
-            if (const char* e = getenv("RFLU_LEAFWISE_ROWS")) lw_rows = atoll(e);
-            f.tail = tail;
-            if (b_deep > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_deep, &U_last));
-            if (b_deep < nblk) RFLU_TRY(factor_deep<T>(f, Wb, b_deep, U_last, lw_rows));
-        } else {
+        {
             if (tail && b_switch == 0) {
                 RFLU_HIP(hipStreamWaitEvent(h->stream, tail, 0));
                 tail = nullptr;
@@ -1363,7 +1045,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last));
             if (b_switch < nblk) RFLU_TRY(factor_leafwise<T>(f, Wb, b_switch, U_last));
         }
-        if (getenv("RFLU_TIME_ENQUEUE"))
+        if (h->tune.time_enqueue)
             fprintf(stderr, "[rflu] host enqueue time %.2f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count());
         fat_tail_done = true;  // the block-column updates already reached the columns right of the square part
@@ -1403,7 +1085,7 @@ static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int6
     }
     *info = 0;
     if (m == 0 || n == 0) return RFLU_OK;
-    const int64_t ldr = workspace_ld(n);
+    const int64_t ldr = workspace_ld(h, n);
     RFLU_TRY(ensure_buffer(&h->work, &h->work_bytes, (size_t)m * (size_t)ldr * sizeof(T)));
     T* R = static_cast<T*>(h->work);
     // Layout change in two pieces: the first block column on the caller's stream, the rest on the CU-masked update stream while
@@ -1411,7 +1093,7 @@ static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int6
     const int64_t mn = std::min(m, n);
     int64_t W0 = blocksize == 0 ? default_blocksize(mn) : blocksize;
     W0 = W0 > 0 ? round_up(W0, NB) : 0;
-    static const bool tail_overlap = [] { const char* e = getenv("RFLU_TAIL_OVERLAP"); return e == nullptr || atoi(e) != 0; }();
+    const bool tail_overlap = h->tune.tail_overlap != 0;
     if (tail_overlap && !h->prof && h->num_cus == 256 && mn >= 12288 && W0 > 0 && W0 < mn && n - W0 >= 4096) {
         if (!h->tail_event_obj) {
             RFLU_HIP(hipEventCreateWithFlags(&h->tail_event_obj, hipEventDisableTiming));
@@ -1491,17 +1173,26 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
     // memory issued next to the running factorization returns only when the factorization has finished (the same call next to a
     // single long kernel does not wait: scripts/probes/d2h_block.hip), so the runtime's staging is of no use here.
     // RFLU_HOST_EARLY_OUT=0: the round-2 sequence (everything after the factorization).
-    static const int64_t chunk = [] { const char* e = getenv("RFLU_HOST_EARLY_OUT"); return e ? atoll(e) : 512; }();
+    const int64_t chunk = h->tune.host_early_out;
     const int64_t W0 = blocksize == 0 ? default_blocksize(mn) : blocksize;
     const bool early = chunk >= 64 && !h->prof && h->num_cus == 256 && mn >= 8192 && W0 > 0 && W0 < mn;
     struct Mark { int64_t r1; std::vector<hipEvent_t> ev; };
     std::vector<Mark> marks;
     size_t ev_used = 0;
     hipStream_t C = nullptr;
+    bool scattered = false;   // finished rows have reached the caller's A (they are taken back if the factorization fails after all)
     struct Reset { Handle* h; ~Reset() { h->progress = nullptr; h->before_sync = nullptr; h->out_done = false; } } reset{h};
     if (early) {
         RFLU_TRY(get_ustream(h, 96, &C));   // a masked stream = a queue of its own that validate_queues can place
         if (h->mask_failed) C = nullptr;
+    }
+    if (early && C) {
+        const size_t bounce_bytes = (size_t)std::min(chunk, m) * (size_t)n * sizeof(T);
+        // outgoing chunks are laid out column-major in a device staging area of their own (two pieces, like the bounce buffers):
+        // the device copy of the INPUT (dA) stays intact until the factorization has succeeded, so that a failure reported
+        // after some rows have already gone home (a panel timeout or placement error is only known at the end) can give the
+        // caller its matrix back, bit for bit
+        if (ensure_buffer(&h->out_stage, &h->out_stage_bytes, 2 * bounce_bytes) != RFLU_OK) C = nullptr;
     }
     if (early && C) {
         const size_t bounce_bytes = (size_t)std::min(chunk, m) * (size_t)n * sizeof(T);
@@ -1552,7 +1243,7 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
             }
             return RFLU_OK;
         };
-        h->progress = [&marks, mark_all, m](int64_t r) -> int {
+        h->progress = [&marks, mark_all, m, chunk](int64_t r) -> int {
             const int64_t have = marks.empty() ? 0 : marks.back().r1;
             r = std::min(r, m);
             // far from the end: whole chunks; within one chunk of the end: every report (one block column at a time)
@@ -1572,10 +1263,10 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
                     }
                 }
             }
-            const int64_t ldr = workspace_ld(n);
+            const int64_t ldr = workspace_ld(h, n);
             const T* R = static_cast<const T*>(h->work);
             const hipStream_t saved = h->stream;
-            const bool trace = getenv("RFLU_HOST_TRACE") != nullptr;
+            const bool trace = h->tune.host_trace != 0;
             auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
             if (trace) fprintf(stderr, "[rflu] host entry: enqueue done %.1f ms after the call (%.1f after the copy in), %zu chunks\n", since(t_call), since(t_in), marks.size());
             const size_t nchunks = marks.size();
@@ -1589,25 +1280,23 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
                 const int64_t r0 = start[k], rows = marks[k].r1 - r0;
                 for (hipEvent_t e : marks[k].ev)
                     if (hipStreamWaitEvent(C, e, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); return RFLU_ERR_HIP; }
+                T* piece = static_cast<T*>(h->out_stage) + (k & 1) * (size_t)std::min(chunk, m) * (size_t)n;
                 h->stream = C;
-                const int rc = launch_transpose<T>(h, n, rows, R + r0 * ldr, ldr, dA + r0 * n, rows);
+                const int rc = launch_transpose<T>(h, n, rows, R + r0 * ldr, ldr, piece, rows);
                 h->stream = saved;
                 RFLU_TRY(rc);
-                RFLU_HIP(hipMemcpyAsync(h->bounce[k & 1], dA + r0 * n, (size_t)rows * (size_t)n * sizeof(T), hipMemcpyDeviceToHost, C));
+                RFLU_HIP(hipMemcpyAsync(h->bounce[k & 1], piece, (size_t)rows * (size_t)n * sizeof(T), hipMemcpyDeviceToHost, C));
                 RFLU_TRY(new_event(&landed[k]));
                 RFLU_HIP(hipEventRecord(landed[k], C));
                 return RFLU_OK;
             };
-            static const int nthreads = [] {
-                const char* e = getenv("RFLU_HOST_THREADS");
-                const int v = e ? atoi(e) : 8;
-                return std::max(1, std::min(v, 64));
-            }();
+            const int nthreads = std::max(1, std::min(h->tune.host_threads, 64));
             for (size_t k = 0; k < std::min<size_t>(2, nchunks); ++k) RFLU_TRY(send(k));
             for (size_t k = 0; k < nchunks; ++k) {
                 RFLU_HIP(hipEventSynchronize(landed[k]));
                 const int64_t r0 = start[k], rows = marks[k].r1 - r0;
                 const T* src = static_cast<const T*>(h->bounce[k & 1]);
+                scattered = true;
                 auto scatter = [&](int64_t j0, int64_t j1) {
                     for (int64_t j = j0; j < j1; ++j) memcpy(A + j * lda + r0, src + j * rows, (size_t)rows * sizeof(T));
                 };
@@ -1635,7 +1324,18 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
             return RFLU_OK;
         };
     }
-    RFLU_TRY(getrf_cm_dev<T>(h, m, n, dA, m, (pivot || want_ipiv) ? h->ipiv_dev : nullptr, pivot, blocksize, info));
+    {
+        const int rc = getrf_cm_dev<T>(h, m, n, dA, m, (pivot || want_ipiv) ? h->ipiv_dev : nullptr, pivot, blocksize, info);
+        if (rc != RFLU_OK) {
+            // A failed call leaves the caller's matrix as it was: rows that went home early are overwritten with the input again
+            // (dA is only ever written after success: the final layout change of getrf_cm_dev).  The error text of rc is kept.
+            if (scattered) {
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy2D(A, (size_t)lda * sizeof(T), dA, (size_t)m * sizeof(T), (size_t)m * sizeof(T), (size_t)n, hipMemcpyDeviceToHost);
+            }
+            return rc;
+        }
+    }
     if (!h->out_done)
         RFLU_HIP(hipMemcpy2DAsync(A, (size_t)lda * sizeof(T), dA, (size_t)m * sizeof(T), (size_t)m * sizeof(T), (size_t)n,
                                   hipMemcpyDeviceToHost, h->stream));
@@ -1718,12 +1418,12 @@ int rflu_create(rflu_handle_t* handle, int device)
         // and competes for CUs with the bulk trailing update on the second stream
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (getenv("RFLU_NO_PRIORITY")) hi = 0;
+        if (env_str("RFLU_NO_PRIORITY")) hi = 0;
         RFLU_HIP(hipStreamCreateWithPriority(&h->own_stream, hipStreamDefault, hi));
     }
     h->stream = h->own_stream;
     RFLU_HIP(hipMalloc((void**)&h->info_dev, 2 * sizeof(int64_t)));
-    if (const char* e = getenv("RFLU_DUMMY_QUEUES")) {
+    if (const char* e = env_str("RFLU_DUMMY_QUEUES")) {
         // measurement / test hook (scripts/queue_collision.py, tests/test_gpu_queues.py): k extra streams created AND USED here,
         // before the update / side streams exist, so that those get other queue indices -- and with them other hardware pipes -- than
         // in a fresh process.  Without validate_queues (RFLU_QUEUE_CHECK=0): N=16384 80 ms or 108-113 ms depending on k.
@@ -1747,10 +1447,7 @@ int rflu_create(rflu_handle_t* handle, int device)
     // runtime how many fit (one 512/576-thread workgroup per CU with these register counts) instead of assuming it.
     h->panel_max_wgs = panel_resident_limit(h->num_cus);
     if (h->panel_max_wgs <= 0) { set_error("occupancy query for the cooperative panel kernels failed"); delete h; return RFLU_ERR_HIP; }
-    if (const char* e = getenv("RFLU_COOP_LAUNCH")) h->coop_launch = atoi(e) != 0;
-    if (const char* e = getenv("RFLU_PANEL_LOCAL")) h->panel_local = atoi(e);
-    if (h->panel_local == 1) h->panel_local_maxg = 32;   // one XCD has 32 CUs
-    if (const char* e = getenv("RFLU_PANEL_LOCAL_MAXG")) h->panel_local_maxg = atoi(e);
+    load_handle_env(h);
     *handle = reinterpret_cast<rflu_handle_t>(h);
     return RFLU_OK;
 }
@@ -1764,6 +1461,7 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->work) (void)hipFree(h->work);
     if (h->ipiv_dev) (void)hipFree(h->ipiv_dev);
     if (h->hostA_dev) (void)hipFree(h->hostA_dev);
+    if (h->out_stage) (void)hipFree(h->out_stage);
     if (h->rhs_work) (void)hipFree(h->rhs_work);
     if (h->hostB_dev) (void)hipFree(h->hostB_dev);
     if (h->pm_cnt) (void)hipFree(h->pm_cnt);
@@ -1808,6 +1506,13 @@ int rflu_synchronize(rflu_handle_t handle)
 {
     CHECK_HANDLE(handle);
     RFLU_HIP(hipStreamSynchronize(H(handle)->stream));
+    return RFLU_OK;
+}
+
+int rflu_reload_tuning(rflu_handle_t handle)
+{
+    if (!handle) { set_error("null handle"); return RFLU_ERR_ARG; }
+    load_handle_env(H(handle));
     return RFLU_OK;
 }
 
@@ -2058,6 +1763,10 @@ struct Rccl {   // resolved lazily: single-GPU users of librflu.so never load RC
 struct Mgpu {
     int ndev = 0;
     bool fake = false;                 // a physical device is named more than once: broadcast = device-to-device copy
+    int64_t ncoll = 0;                 // ncclBroadcast calls enqueued (rflu_mgpu_collectives)
+    bool force_rccl = false;           // RFLU_MGPU_FORCE_RCCL=1 with ONE device: a one-rank communicator and the grouped broadcast-to-self, so
+                                       // that the collective's code path (dlopen, ncclCommInitAll, ncclBroadcast on the panel stream) can be
+                                       // executed and tested on a box with a single GPU
     std::vector<int> devs;
     std::vector<Handle*> h;            // one handle (streams, workspaces, exchange scratch) per logical device
     std::vector<ncclComm_t> comms;     // real multi-GPU only
@@ -2113,11 +1822,9 @@ static int mgpu_update(Handle* h, int64_t n, T* R, int64_t ld, const T* pb, int6
 }
 
 // CUs the next owner of a tall panel keeps away from its share of the update (mgpu_getrf); RFLU_MGPU_BIG_RESERVE overrides
-static int64_t mgpu_big_reserve()
+static int64_t mgpu_big_reserve(const Handle* h)
 {
-    int64_t v = 128;
-    if (const char* e = getenv("RFLU_MGPU_BIG_RESERVE")) v = std::min<int64_t>(224, std::max<int64_t>(0, atoll(e) / 32 * 32));
-    return v;
+    return std::min<int64_t>(224, std::max<int64_t>(0, h->tune.mgpu_big_reserve / 32 * 32));
 }
 
 template <typename T>
@@ -2168,7 +1875,7 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
             // the streams this device will run side by side -- panel stream, 32-CU mask and (next owner of a tall panel) the big
             // mask -- on different hardware pipes (validate_queues); logical devices on one GPU share its 4 pipes anyway
             hipStream_t big;
-            if (D > 1 && mgpu_big_reserve() > 32) RFLU_TRY(get_ustream(h, (int)mgpu_big_reserve(), &big));
+            if (D > 1 && mgpu_big_reserve(h) > 32) RFLU_TRY(get_ustream(h, (int)mgpu_big_reserve(h), &big));
             h->stream = g->P[d];
             RFLU_TRY(validate_queues(h));
             RFLU_TRY(get_ustream(h, 32, &g->U[d]));   // may have been replaced
@@ -2230,12 +1937,13 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
             RFLU_TRY(EV(o, b, 0, &e));
             RFLU_HIP(hipEventRecord(e, g->P[o]));
         }
-        if (D == 1) return RFLU_OK;
+        if (D == 1 && !g->force_rccl) return RFLU_OK;
         if (!g->fake) {   // the one exchange step of the path: ncclBroadcast of {panel, pivots} on the panel streams
             RFLU_NCCL(g->rccl, g->rccl.GroupStart());
             for (int d = 0; d < D; ++d) {
                 RFLU_NCCL(g->rccl, g->rccl.Broadcast(g->pbuf[par][d], g->pbuf[par][d], (size_t)rows * (size_t)c.w, ntype, o, g->comms[d], g->P[d]));
                 RFLU_NCCL(g->rccl, g->rccl.Broadcast(g->meta[par][d], g->meta[par][d], (size_t)c.w, ncclInt64, o, g->comms[d], g->P[d]));
+                g->ncoll += 2;
             }
             RFLU_NCCL(g->rccl, g->rccl.GroupEnd());
             for (int d = 0; d < D; ++d) {
@@ -2267,11 +1975,14 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
     // reservation (ONE extra stream per device: panel stream, 32-CU mask, big mask -- three streams on three of the four hardware
     // pipes, placed by validate_queues).  Only a panel that needs even more is factored BEFORE the owner's bulk update (round 2 did that from 16384
     // rows on: at N=65536 over 8 GPUs 96 of 128 block columns, ~0.3 s of un-overlapped panels).
-    const int64_t big_reserve = mgpu_big_reserve();
-    int64_t tall_rows = std::max<int64_t>(32, big_reserve) * (int64_t)PANEL_THREADS;
-    if (const char* e = getenv("RFLU_MGPU_TALL_ROWS")) tall_rows = atoll(e);     // debugging knobs
+    const Tune& tune0 = g->h[0]->tune;
+    const int64_t big_reserve = mgpu_big_reserve(g->h[0]);
+    // (one device has no big-reserve stream -- it is only created for D > 1: its panels taller than the usual 32-CU reservation
+    //  holds are factored before the bulk update, as in round 2)
+    int64_t tall_rows = (D > 1 ? std::max<int64_t>(32, big_reserve) : 32) * (int64_t)PANEL_THREADS;
+    if (tune0.mgpu_tall_rows >= 0) tall_rows = tune0.mgpu_tall_rows;     // debugging knobs
     std::vector<hipStream_t> Ucur(g->U);   // the stream that carried each device's previous update
-    const int dbg_sync = getenv("RFLU_MGPU_SYNC") ? atoi(getenv("RFLU_MGPU_SYNC")) : 0;
+    const int dbg_sync = tune0.mgpu_sync;
     auto sync_all = [&]() -> int {
         for (int d = 0; d < D; ++d) { RFLU_HIP(hipSetDevice(g->devs[d])); RFLU_HIP(hipDeviceSynchronize()); }
         return RFLU_OK;
@@ -2422,7 +2133,8 @@ int rflu_mgpu_create(rflu_mgpu_t* out, int ndev, const int* devs)
         rc = rflu_create(&hh, devs[d]);
         if (rc == RFLU_OK) g->h.push_back(H(hh));
     }
-    if (rc == RFLU_OK && ndev > 1 && !g->fake) {   // RCCL communicator over the distinct devices (single process)
+    if (const char* e = env_str("RFLU_MGPU_FORCE_RCCL")) g->force_rccl = atoi(e) != 0 && ndev == 1;
+    if (rc == RFLU_OK && (ndev > 1 || g->force_rccl) && !g->fake) {   // RCCL communicator over the distinct devices (single process)
         rc = g->rccl.load();
         if (rc == RFLU_OK) {
             g->comms.assign(ndev, nullptr);
@@ -2461,6 +2173,7 @@ int rflu_mgpu_destroy(rflu_mgpu_t m)
 
 int rflu_mgpu_ndev(rflu_mgpu_t m) { return m ? MG(m)->ndev : 0; }
 int rflu_mgpu_is_fake(rflu_mgpu_t m) { return m ? (MG(m)->fake ? 1 : 0) : 0; }
+int64_t rflu_mgpu_collectives(rflu_mgpu_t m) { return m ? MG(m)->ncoll : 0; }
 
 int64_t rflu_mgpu_local_cols(int64_t n, int64_t block, int ndev, int64_t run, int d)
 {

@@ -414,11 +414,9 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
     constexpr int VW = 16 / (int)sizeof(T);
     g.vec_ok = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16 == 0) && (lda % VW == 0) &&
                (ldb % VW == 0);
-    static const int gemm_flags = [] { const char* e = getenv("RFLU_GEMM_FLAGS"); return e ? atoi(e) : 1; }();
-    g.flags = gemm_flags;
+    g.flags = h->tune.gemm_flags;
     {   // small K, few tiles: the latency-optimised kernel (measured crossover, scripts/microbench_gemm_small.py)
-        static const int skinny_max_k = [] { const char* e = getenv("RFLU_SKINNY_MAXK"); return e ? atoi(e) : 128; }();
-        static const int skinny_wide = [] { const char* e = getenv("RFLU_SKINNY_WIDE"); return e ? atoi(e) : 0; }();
+        const int skinny_max_k = h->tune.skinny_max_k, skinny_wide = h->tune.skinny_wide;
         if (g.vec_ok && (K == S_KC || K == 2 * S_KC) && K <= skinny_max_k && (N <= 2 * K || (skinny_wide && K == S_KC))) {
             g.tiles_m = (int)((M + S_BM - 1) / S_BM);
             g.tiles_n = (int)((N + S_BN - 1) / S_BN);
@@ -453,7 +451,7 @@ int launch_gemm(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, int64_t 
     // large K (15360^2 x K, TFLOP/s: K=1024 62.7 -> 67.2, 2048 67.4 -> 69.2, 4096 68.0 -> 69.7; N=65536 3219 -> 3124 ms); round 2
     // switched to the late read-modify-write from K = 1024 on because the per-slab negation cost more there
     // (RFLU_GEMM_CFIRST_BELOW=1024 restores that)
-    static const int64_t cfirst_below = [] { const char* e = getenv("RFLU_GEMM_CFIRST_BELOW"); return e ? atoll(e) : (int64_t)1 << 40; }();
+    const int64_t cfirst_below = h->tune.gemm_cfirst_below;
     if (K < cfirst_below) hipLaunchKernelGGL((gemm_sub_kernel<T, true>), dim3((unsigned)nwg), dim3(256), lds, h->stream, g);
     else          hipLaunchKernelGGL((gemm_sub_kernel<T, false>), dim3((unsigned)nwg), dim3(256), lds, h->stream, g);
     RFLU_HIP(hipGetLastError());

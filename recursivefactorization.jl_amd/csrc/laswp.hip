@@ -156,8 +156,7 @@ int launch_laswp3(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64
                      (ncolsC == 0 || (c2 % VWF == 0 && ncolsC % VWF == 0));
     // lanes per row segment: 8 x 16 bytes = one 128-byte line (RFLU_LASWP_LPR=4: half-line segments, twice the waves -- measured
     // no better: 2.97 vs 3.16 TB/s on the wide launches of an N=16384 factorization)
-    static const int lpr_env = [] { const char* e = getenv("RFLU_LASWP_LPR"); return e ? atoi(e) : 0; }();
-    const int lpr = lpr_env == 4 ? 4 : 8;
+    const int lpr = h->tune.laswp_lpr == 4 ? 4 : 8;
     const int64_t SC = lpr * (vec ? VWF : 1);
     const int64_t strips = (ncolsA + SC - 1) / SC + (ncolsB + SC - 1) / SC + (ncolsC + SC - 1) / SC;
     int64_t blocks = (strips + LW_WAVES - 1) / LW_WAVES + inv_cnt;

@@ -326,464 +326,6 @@ __global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_kernel(PanelArgs<T>
 }
 
 // =====================================================================================================================
-// Pipelined pivoted leaf (two or more workgroups).  The kernel above spends two DEPENDENT trips through the coherent
-// memory path per column: the headers (who wins?), then the winner's row.  Here a header also carries the candidate row's
-// NEXT-column entry u.  Once the headers of column k are in, every workgroup knows the pivot and u_{k,k+1}: it brings
-// column k+1 up to date with one multiply-add per row and starts the search for the next pivot at once -- while the
-// winner's row (columns k+2..) is still travelling.  The row is needed only when the next candidate row is published; the
-// rank-1 update of all the other rows runs behind that, next to the following header trip.
-//   per column:  poll headers(k) -> [bookkeeping, column k+1, search k+1]  ||  row(k) in flight  -> publish candidate(k+1)
-// Same arithmetic on every entry as the kernel above (each a[j] receives the same multiply-adds in the same order).
-// =====================================================================================================================
-template <typename T>
-struct PipeLds {
-    T prow[2][NB];             // pivot rows of the last two steps (columns k+2.. valid), by step parity
-    T wval[PANEL_WAVES];
-    unsigned wpos[PANEL_WAVES];
-    unsigned win[2];           // pivot position, by step parity
-    T unext[2];                // winner's entry in column k+1
-    int dead;
-    int rows[NB];
-};
-
-
-// search of one column inside the workgroup: 1 = this thread owns the workgroup's candidate row, 2 = no candidate at all
-// (returned to thread 0, which publishes an empty header), 0 otherwise.  One workgroup barrier.
-template <typename T>
-__device__ __forceinline__ int pipe_front(PipeLds<T>* sh, T aval, unsigned pos, bool act, int tid)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    T key = T(-1);
-    unsigned p = POS_NONE;
-    if (act) {
-        const T v = tabs(aval);
-        key = (v > T(0)) ? v : T(0);  // NaN and 0 -> 0: never preferred, ties -> lowest position (src/lu.jl:298-304)
-        p = pos;
-    }
-    wave_argmax<T>(key, p);
-    if (lane == 0) { sh->wval[wave] = key; sh->wpos[wave] = p; }
-    barrier_lds_only();
-    T kx[PANEL_WAVES];
-    unsigned px[PANEL_WAVES];
-#pragma unroll
-    for (int x = 0; x < PANEL_WAVES; ++x) { kx[x] = sh->wval[x]; px[x] = sh->wpos[x]; }
-    const T cv = tmax(tmax(tmax(kx[0], kx[1]), tmax(kx[2], kx[3])), tmax(tmax(kx[4], kx[5]), tmax(kx[6], kx[7])));
-    unsigned c[PANEL_WAVES];
-#pragma unroll
-    for (int x = 0; x < PANEL_WAVES; ++x) c[x] = (kx[x] == cv) ? px[x] : POS_NONE;
-    const unsigned cp = min(min(min(c[0], c[1]), min(c[2], c[3])), min(min(c[4], c[5]), min(c[6], c[7])));
-    if (act && pos == cp) return 1;
-    if (cp == POS_NONE && tid == 0) return 2;
-    return 0;
-}
-
-// flags: bit0 apply the update to this row, bit1 row still active, bit2 give up, bit3 this thread owns the workgroup's
-// candidate row for the NEXT column, bit4 (thread 0) the workgroup has no candidate for the next column
-template <typename T>
-__device__ __noinline__ MidOut<T> pipe_mid(PipeLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch, int G,
-                                           int k, int w, int r0, int g, int tid, T ak, T ak1, unsigned pos, bool act)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    const int par = k & 1;
-    const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(scratch);
-    const unsigned tag = epoch + (unsigned)k;
-    const unsigned base = (unsigned)par * PS_BUF_BYTES;
-    typename Gran<T>::raw_t raw;
-    bool want_row = false;
-    unsigned roff = 0;
-    RFLU_STAMP(scratch, k, 0, g, tid);
-    // EVERY wave polls the headers and reduces them on its own: no hand-over through LDS, no barrier before the bookkeeping
-    bool timed_out = false;
-    T gv = T(-1), ga = T(0), gu = T(0);
-    unsigned gp = POS_NONE;
-    int gg = 0;
-    for (int x = lane; x < G; x += 64) {
-        int spins = 0;
-        for (;;) {
-            unsigned xp;
-            T xv, xu;
-            asm volatile("" ::: "memory");  // plain buffer intrinsics: keep the loads inside the loop
-            if (Gran<T>::load_hdr3(rs, base + (unsigned)x * PS_HDR_BYTES, tag, xp, xv, xu)) {
-                if (xp != POS_NONE) {
-                    const T av = tabs(xv);
-                    const T xk = (av > T(0)) ? av : T(0);
-                    if (better<T>(xk, xp, gv, gp)) { gv = xk; gp = xp; gg = x; ga = xv; gu = xu; }
-                }
-                break;
-            }
-            if (++spins > SPIN_LIMIT) { timed_out = true; break; }
-            if (spins > 4) __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    {
-        const T mykey = gv;
-        const unsigned mypos = gp;
-        wave_argmax<T>(gv, gp);
-        const u64 who = __ballot(mykey == gv && mypos == gp && mypos != POS_NONE);
-        const int wl = who ? (__ffsll((long long)who) - 1) : 0;
-        gg = __builtin_amdgcn_readlane(gg, wl);
-        ga = readlane_val(ga, wl);
-        gu = readlane_val(gu, wl);
-    }
-    RFLU_STAMP(scratch, k, 1, g, tid);
-    if (__any(timed_out)) {
-        gp = POS_NONE;
-        if (lane == 0) {
-            __hip_atomic_store((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh->dead = 1;
-        }
-    }
-    if (wave == 0) {
-        if (gp != POS_NONE && lane >= k + 2 && lane < NB) {  // the winner's row: requested now, looked at after the search
-            roff = base + PS_HDR_REGION + (unsigned)gg * PS_ROW_BYTES + (unsigned)lane * PS_VAL_BYTES;
-            raw = Gran<T>::load_raw(rs, roff);
-            want_row = true;
-        }
-        if (lane == 0) {   // for the caller (read after the barriers below)
-            sh->win[par] = gp;
-            sh->unext[par] = gu;
-        }
-    }
-    RFLU_STAMP(scratch, k, 2, g, tid);
-    MidOut<T> o;
-    o.scale = T(1);
-    o.pos = pos;
-    o.flags = act ? 2u : 0u;
-    T a1 = ak1;
-    const unsigned win_pos = gp;
-    if (win_pos != POS_NONE) {
-        const unsigned kpos = (unsigned)(r0 + k);
-        if (g == 0 && tid == 0) {
-            ipiv[r0 + k] = (int64_t)win_pos + 1;
-            if (ga == T(0) && info[0] == 0) info[0] = (int64_t)r0 + k + 1;
-        }
-        o.scale = (ga != T(0)) ? T(1) / ga : T(1);
-        if (act) {
-            if (pos == win_pos) {
-                o.pos = kpos;      // pivot row: final position r0+k, no further updates
-                o.flags &= ~2u;
-            } else {
-                if (pos == kpos) o.pos = win_pos;  // displaced row takes the pivot's old position
-                o.flags |= 1u;
-                a1 = ak1 - (ak * o.scale) * gu;   // column k+1 is current before the row arrives
-            }
-        }
-    }
-    if (k + 1 < w) {   // search of column k+1 (workgroup-uniform condition; a timed-out workgroup still meets its barriers)
-        const int f = pipe_front<T>(sh, a1, o.pos, (o.flags & 2u) != 0, tid);
-        if (f == 1) o.flags |= 8u;
-        if (f == 2) o.flags |= 16u;
-    }
-    RFLU_STAMP(scratch, k, 3, g, tid);
-    if (wave == 0 && want_row) {
-        T xv = T(0);
-        if (!Gran<T>::unpack(raw, tag, xv)) {
-            int spins = 0;
-            for (;;) {
-                asm volatile("" ::: "memory");
-                if (Gran<T>::load(rs, roff, tag, xv)) break;
-                if (++spins > SPIN_LIMIT) {
-                    __hip_atomic_store((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sh->dead = 1;
-                    break;
-                }
-            }
-        }
-        sh->prow[par][lane] = xv;
-    }
-    __syncthreads();
-    RFLU_STAMP(scratch, k, 4, g, tid);
-    if (sh->dead) o.flags |= 4u;
-    return o;
-}
-
-// publish the workgroup's candidate for column kc: header {pos, a[kc], a[kc+1]} first, then the row from column kc+2 on
-template <typename T, int KC>
-__device__ __forceinline__ void pipe_publish(const PanelArgs<T>& p, const T (&a)[NB], unsigned pos, int g)
-{
-    const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(p.scratch);
-    const unsigned tag = p.epoch + (unsigned)KC;
-    const unsigned base = (unsigned)(KC & 1) * PS_BUF_BYTES;
-    T un = T(0);
-    if constexpr (KC + 1 < NB) un = a[KC + 1];
-    Gran<T>::store_hdr3(rs, base + (unsigned)g * PS_HDR_BYTES, tag, pos, a[KC], un);
-    const unsigned roff = base + PS_HDR_REGION + (unsigned)g * PS_ROW_BYTES;
-#pragma unroll
-    for (int j = KC + 2; j < NB; ++j) Gran<T>::store(rs, roff + j * PS_VAL_BYTES, tag, a[j]);
-}
-
-template <typename T, int K>
-__device__ __forceinline__ void pipe_step(const PanelArgs<T>& p, PipeLds<T>* sh, T (&a)[NB], unsigned& pos, bool& act,
-                                          bool& dead, PermState& perm, int g, int tid)
-{
-    if (K >= p.w || dead) return;
-    T ak1 = T(0);
-    if constexpr (K + 1 < NB) ak1 = a[K + 1];
-    const MidOut<T> o = pipe_mid<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, K, p.w, p.r0, g, tid, a[K], ak1, pos, act);
-    pos = o.pos;
-    act = (o.flags & 2u) != 0;
-    dead = (o.flags & 4u) != 0;
-    if (dead) return;
-    if (g == 0 && (tid >> 6) == PANEL_WAVES - 1) {
-        const unsigned wp = sh->win[K & 1];
-        if (wp != POS_NONE) perm_state_step(perm, p.r0, K, __builtin_amdgcn_readfirstlane((int)wp), tid & 63);
-    }
-    T l = T(0);
-    if (o.flags & 1u) {
-        l = a[K] * o.scale;  // reciprocal-multiply (src/lu.jl:317-320); scale == 1 after a zero pivot
-        a[K] = l;
-        if constexpr (K + 1 < NB) a[K + 1] -= l * sh->unext[K & 1];
-    }
-    const T* prow = sh->prow[K & 1];
-    const bool upd = (o.flags & 1u) != 0;
-    const bool cand = (o.flags & 8u) != 0 && K + 1 < p.w;   // this row is the workgroup's candidate for column K+1
-    if constexpr (K + 1 < NB) {
-        // Everybody brings column K+2 up to date (one multiply-add), then the candidate's header leaves BEFORE any of the
-        // long update loops: inside a divergent if/else hipcc ran the other 63 lanes' update first and the header waited
-        // ~450 ns for it (scripts/panel_skew_trace.py: barrier 3 -> header out 744 ns).
-        const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(p.scratch);
-        const unsigned tag = p.epoch + (unsigned)(K + 1);
-        const unsigned base = (unsigned)((K + 1) & 1) * PS_BUF_BYTES;
-        T un = T(0);
-        if constexpr (K + 2 < NB) {
-            if (upd) a[K + 2] -= l * prow[K + 2];
-            un = a[K + 2];
-        }
-        if (cand) {
-            Gran<T>::store_hdr3(rs, base + (unsigned)g * PS_HDR_BYTES, tag, pos, a[K + 1], un);
-            RFLU_STAMP_ANY(p.scratch, K, 6, g);
-        } else if ((o.flags & 16u) && K + 1 < p.w) {   // nobody left in this workgroup: an empty header keeps the others going
-            Gran<T>::store_hdr3(rs, base + (unsigned)g * PS_HDR_BYTES, tag, POS_NONE, T(0), T(0));
-        }
-        asm volatile("" ::: "memory");   // keep the header store ahead of the loops below
-        if (cand) {
-            const unsigned roff = base + PS_HDR_REGION + (unsigned)g * PS_ROW_BYTES;
-#pragma unroll
-            for (int j = K + 3; j < NB; ++j) {
-                a[j] -= l * prow[j];
-                Gran<T>::store(rs, roff + j * PS_VAL_BYTES, tag, a[j]);
-            }
-        } else if (upd) {
-#pragma unroll
-            for (int j = K + 3; j < NB; ++j) a[j] -= l * prow[j];
-        }
-    }
-    RFLU_STAMP(p.scratch, K, 5, g, tid);
-}
-
-template <typename T, int K0, int K1>
-struct PipeSteps {
-    static __device__ __forceinline__ void run(const PanelArgs<T>& p, PipeLds<T>* sh, T (&a)[NB], unsigned& pos,
-                                               bool& act, bool& dead, PermState& perm, int g, int tid)
-    {
-        if constexpr (K0 < K1) {
-            pipe_step<T, K0>(p, sh, a, pos, act, dead, perm, g, tid);
-            PipeSteps<T, K0 + 1, K1>::run(p, sh, a, pos, act, dead, perm, g, tid);
-        }
-    }
-};
-
-template <typename T>
-__global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_pipe_kernel(PanelArgs<T> p)
-{
-    __shared__ PipeLds<T> s_lds;
-    PipeLds<T>* const sh = &s_lds;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x;
-    const int row = p.r0 + g * PANEL_THREADS + tid;
-    bool act = row < p.m;
-    unsigned pos = act ? (unsigned)row : POS_NONE;
-    if (tid == 0) sh->dead = 0;
-    T a[NB];
-    load_row_direct<T>(p.R, p.ld, row, act, p.c0, p.w, a);
-    __syncthreads();
-    {   // column 0: search and publish
-        const int f = pipe_front<T>(sh, a[0], pos, act, tid);
-        if (f == 1) pipe_publish<T, 0>(p, a, pos, g);
-        if (f == 2) Gran<T>::store_hdr3(scratch_rsrc(p.scratch), (unsigned)g * PS_HDR_BYTES, p.epoch, POS_NONE, T(0), T(0));
-    }
-    bool dead = false;
-    PermState perm = perm_state_init(lane);
-    PipeSteps<T, 0, NB>::run(p, sh, a, pos, act, dead, perm, g, tid);
-    store_row_direct<T>(p.R, p.ld, pos, p.c0, p.w, a);
-    __syncthreads();
-    if (g == 0 && wave == PANEL_WAVES - 1) {
-        const int chunk = p.r0 / NB;
-        perm_state_finish(perm, p.r0, lane, sh->rows, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
-                          p.pm_src + (size_t)chunk * 2 * NB);
-    }
-}
-
-// =====================================================================================================================
-// Pair leaf: two adjacent 64-column leaves (columns [c0, c0+64) and [c0+64, c0+128)) in ONE cooperative launch.
-// Between the two leaves the recursion would run  interchanges -> 64x64 unit-lower solve -> K=64 Schur update
-// (src/lu.jl:233-240 at the lowest level) as three dependent launches; here every thread does that for its own row:
-//   * leaf A's interchanges on leaf B's columns are implicit: a thread keeps its row (tracking its position) and reads the
-//     row's leaf-B part from where it physically still lies;
-//   * the 64 pivot-row owners publish {their L11 row, their raw leaf-B row}; every workgroup gathers the 64 slots and
-//     solves U12 = L11^-1 * B_piv redundantly in LDS (forward substitution, 64 steps);
-//   * every other row subtracts l_i * U12 from its leaf-B part in registers (l_i re-read from the row it just stored).
-// Leaf B then runs on the same registers.  Its interchanges still have to reach leaf A's columns: the caller's laswp
-// launch does that (chunk B on columns [c0, c0+64)).
-// =====================================================================================================================
-template <typename T>
-struct PairLds {
-    T ltri[NB * (NB - 1) / 2];   // strictly lower part of L11, packed by rows: (k,t) at k(k-1)/2 + t
-    T u12[NB * PX_UL];           // raw leaf-B rows of the 64 pivots, then U12 (row stride PX_UL)
-};
-
-template <typename T>
-__global__ void __launch_bounds__(PANEL_THREADS) panel_pivot_pair_kernel(PanelArgs<T> p)
-{
-    __shared__ PivotLds<T> s_lds;
-    __shared__ PairLds<T> s_pair;
-    PivotLds<T>* const sh = &s_lds;
-    PairLds<T>* const px = &s_pair;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x;
-    const int row_base = p.r0 + g * PANEL_THREADS;
-    const int row = row_base + tid;
-    const bool valid = row < p.m;
-    bool act = valid;
-    unsigned pos = valid ? (unsigned)row : POS_NONE;
-    if (tid == 0) sh->dead = 0;
-    T a[NB];
-    load_row_direct<T>(p.R, p.ld, row, valid, p.c0, NB, a);
-    __syncthreads();
-
-    PanelArgs<T> q = p;
-    q.w = NB;
-    bool dead = false;
-    PermState perm = perm_state_init(lane);
-    bool pivot_a = false;   // this thread's row became one of leaf A's pivots (position r0 + ka)
-    int ka = 0;
-#pragma nounroll
-    for (int phase = 0; phase < 2; ++phase) {
-        PivotSteps<T, 0, NB>::run(q, sh, a, pos, act, dead, perm, g, tid);
-        if (phase == 1 || dead) break;
-
-        // ---------------- between the leaves ----------------
-        RFLU_STAMP(p.scratch, NB, 4, g, tid);
-        const __amdgpu_buffer_rsrc_t rx = pair_rsrc(p.scratch);
-        const unsigned tagx = p.epoch + 2u * NB;
-        pivot_a = valid && !act;
-        ka = pivot_a ? (int)pos - p.r0 : 0;
-        if (pivot_a) {  // L11 row (columns < ka are L, the rest is U11 and ignored by the readers)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) Gran<T>::store(rx, (unsigned)ka * PX_SLOT_BYTES + j * PS_VAL_BYTES, tagx, a[j]);
-        }
-        store_row_direct<T>(p.R, p.ld, pos, p.c0, NB, a);               // leaf A's part goes to the row's position
-        if (g == 0 && wave == PANEL_WAVES - 1) {                        // chunk A's move list; fresh state for leaf B
-            const int chunk = p.r0 / NB;
-            perm_state_finish(perm, p.r0, lane, sh->rows, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
-                              p.pm_src + (size_t)chunk * 2 * NB);
-            perm = perm_state_init(lane);
-        }
-        load_row_direct<T>(p.R, p.ld, row, valid, p.c0 + NB, NB, a);    // leaf B's part: still at the row's ORIGINAL place
-        if (pivot_a) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-                Gran<T>::store(rx, (unsigned)ka * PX_SLOT_BYTES + (NB + j) * PS_VAL_BYTES, tagx, a[j]);
-        }
-        RFLU_STAMP(p.scratch, NB, 5, g, tid);
-        // gather the 64 slots: 2*NB*NB granules, 16 per thread, all loads in flight before the first tag is checked
-        {
-            constexpr int PER = (2 * NB * NB) / PANEL_THREADS, BATCH = 8;
-            bool timed_out = false;
-#pragma unroll
-            for (int i0 = 0; i0 < PER; i0 += BATCH) {
-                typename Gran<T>::raw_t raw[BATCH];
-#pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    const int idx = (i0 + i) * PANEL_THREADS + tid;
-                    raw[i] = Gran<T>::load_raw(rx, (unsigned)(idx >> 7) * PX_SLOT_BYTES + (unsigned)(idx & (2 * NB - 1)) * PS_VAL_BYTES);
-                }
-#pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    const int idx = (i0 + i) * PANEL_THREADS + tid;
-                    const int slot = idx >> 7, j = idx & (2 * NB - 1);
-                    T v = T(0);
-                    if (!Gran<T>::unpack(raw[i], tagx, v)) {
-                        int spins = 0;
-                        for (;;) {
-                            asm volatile("" ::: "memory");
-                            if (Gran<T>::load(rx, (unsigned)slot * PX_SLOT_BYTES + (unsigned)j * PS_VAL_BYTES, tagx, v)) break;
-                            if (++spins > SPIN_LIMIT) { timed_out = true; break; }
-                            if (spins > 4) __builtin_amdgcn_s_sleep(1);
-                        }
-                    }
-                    if (j >= NB) px->u12[slot * PX_UL + (j - NB)] = v;
-                    else if (j < slot) px->ltri[slot * (slot - 1) / 2 + j] = v;
-                }
-            }
-            if (timed_out) {
-                __hip_atomic_store((u64*)(p.info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh->dead = 1;
-            }
-        }
-        __syncthreads();
-        if (sh->dead) { dead = true; break; }
-        RFLU_STAMP(p.scratch, NB, 6, g, tid);
-        // U12 = L11^-1 * B_piv in LDS, right-looking: row t is final after step t-1; rows k > t (one per wave and
-        // round) subtract L11[k][t] * U12[t].  Lane = column.  (A per-wave variant without workgroup barriers -- every
-        // wave solving 8 columns on its own -- measured slower: 31 vs 24 us.)
-#pragma nounroll
-        for (int t = 0; t < NB - 1; ++t) {
-            const T ut = px->u12[t * PX_UL + lane];
-            for (int k = t + 1 + wave; k < NB; k += PANEL_WAVES)
-                px->u12[k * PX_UL + lane] -= px->ltri[k * (k - 1) / 2 + t] * ut;
-            __syncthreads();
-        }
-        RFLU_STAMP(p.scratch, NB, 7, g, tid);
-        // Schur update of this row's leaf-B part: b -= l * U12, l = the leaf-A part stored above.  U12 rows are read
-        // from LDS (same address in every lane) 16 values at a time; the fences bound how far hipcc hoists those reads.
-        // This is LDS-bandwidth bound (64 x 8 B returned per multiply-add: ~40 us per pair).  Feeding the values through
-        // the scalar unit instead (U12 parked in global scratch, s_load -> SGPR operands) measured 55-120 us: hipcc waits
-        // for every 64-byte scalar load before its 8 multiply-adds.  The fix is an MFMA formulation.
-        if (act) {
-            constexpr int LC = 8, UG = 16;
-            const T* lrow = p.R + (int64_t)pos * p.ld + p.c0;
-#pragma nounroll
-            for (int c = 0; c < NB / LC; ++c) {
-                T l[LC];
-#pragma unroll
-                for (int e = 0; e < LC; ++e) l[e] = lrow[c * LC + e];
-#pragma unroll
-                for (int e = 0; e < LC; ++e) {
-                    const T* urow = &px->u12[(c * LC + e) * PX_UL];
-#pragma unroll
-                    for (int j0 = 0; j0 < NB; j0 += UG) {
-                        T uv[UG];
-#pragma unroll
-                        for (int j = 0; j < UG; ++j) uv[j] = urow[j0 + j];
-                        asm volatile("" ::: "memory");
-#pragma unroll
-                        for (int j = 0; j < UG; ++j) a[j0 + j] -= l[e] * uv[j];
-                    }
-                }
-            }
-        }
-        RFLU_STAMP(p.scratch, NB, 8, g, tid);
-        q.r0 += NB;
-        q.c0 += NB;
-        q.epoch += NB;
-    }
-
-    if (pivot_a && !dead) {  // leaf A's pivot rows: their leaf-B part is a row of U12
-#pragma unroll
-        for (int j = 0; j < NB; ++j) a[j] = px->u12[ka * PX_UL + j];
-    }
-    store_row_direct<T>(p.R, p.ld, pos, p.c0 + NB, NB, a);
-    __syncthreads();
-    if (g == 0 && wave == PANEL_WAVES - 1) {
-        const int chunk = p.r0 / NB + 1;
-        perm_state_finish(perm, p.r0 + NB, lane, sh->rows, p.pm_cnt + chunk, p.pm_dst + (size_t)chunk * 2 * NB,
-                          p.pm_src + (size_t)chunk * 2 * NB);
-    }
-}
-
-// =====================================================================================================================
 // NoPivot leaf panel (Val(false) / NoPivot()): no exchange between workgroups.
 //   kernel 1 (one workgroup): unpivoted LU of the w x w top block, in place.
 //   kernel 2 (G workgroups) : every row below solves  l_i * U11 = a_i  against the factored top block held in LDS.
@@ -975,14 +517,17 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
         h->epoch += (unsigned)NB;
     }
     ProfScope ps(h, RFLU_K_PANEL, (double)rows * (double)w * (double)w);
+    if (pivot && rows <= PANEL_THREADS && h->panel_single) {   // one workgroup, LDS only (panel_single.hip)
+        RFLU_TRY(launch_panel_single<T>(h, p));
+        return RFLU_OK;
+    }
     if (pivot) {
-        // 2..64 workgroups: the pipelined kernel, in which every wave polls one header per lane (RFLU_PIPE=0 selects the
-        // two-trip kernel above, which also serves taller panels: measured 0.5 % faster there)
-        static const bool pipe = [] { const char* e = getenv("RFLU_PIPE"); return e == nullptr || e[0] != '0'; }();
-        // pipelined leaf with a communication wave (panel_local.hip); one header per lane of that wave: at most 64 workgroups
-        static const int64_t local_min = [] { const char* e = getenv("RFLU_PANEL_LOCAL_MIN"); return e ? atoll(e) : 256; }();   // panels of 257..512 rows: 8 workgroups of 64 rows on one XCD instead of the one-workgroup leaf (N=1024 2.59 -> 2.51 ms)
+        // Full leaves of 2..64 workgroups: the pipelined cooperative leaf with a communication wave (panel_local.hip; one header
+        // per lane of that wave).  A narrower last leaf (w < NB, matrices whose width is no multiple of 64) and RFLU_PANEL_LOCAL=0
+        // take the two-trip kernel above.
+        const int64_t local_min = h->tune.panel_local_min;   // panels of 257..512 rows with RFLU_PANEL_SINGLE=0: 8 workgroups of 64 rows on one XCD
         const bool tiny_local = h->panel_local == 2 && h->num_cus == 256 && rows > local_min && rows <= 512 && !h->coop_launch;
-        if (h->panel_local > 0 && (p.G >= 2 || tiny_local) && p.G <= std::min(h->panel_local_maxg, 64)) {
+        if (h->panel_local > 0 && w == NB && (p.G >= 2 || tiny_local) && p.G <= std::min(h->panel_local_maxg, 64)) {
             // Panels of at most 4096 rows (<= 16 workgroups of 256 rows) run the XCD-local variant: all participants on ONE XCD, plain-store
             // records that stay in that XCD's L2, a 0.34 us hop instead of 0.56-0.75.  The launch has 8 G workgroups of which the 7 G on
             // the other XCDs exit at once; they still have to be placed, which next to a big update costs more than the hop saves (N=8192
@@ -991,19 +536,14 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
             // N=8192).  RFLU_PANEL_LOCAL_ROWS=0 switches it off, RFLU_PANEL_LOCAL=1 forces it for every panel.
             // Float32: the update is half as heavy, the 32 participants of an 8192-row panel still find their XCD (N=16384 61.9 -> 59.9-60.7 ms,
             // N=8192 22.45 -> 22.18; 12288 rows: 62.1)
-            const int64_t local_rows = [] { const char* e = getenv("RFLU_PANEL_LOCAL_ROWS"); return e ? atoll(e) : (sizeof(T) == 4 ? 8192 : 4096); }();   // (read per launch: tests switch it)
+            const int64_t local_rows = h->tune.panel_local_rows >= 0 ? h->tune.panel_local_rows : (sizeof(T) == 4 ? 8192 : 4096);
             const bool loc = h->panel_local == 1 || (h->num_cus == 256 && rows <= local_rows && (rows > 512 || tiny_local));
             RFLU_TRY(launch_panel_local<T>(h, p, loc ? 8 : 1, loc ? h->panel_xcc : 0, loc ? h->panel_xcc : -1, loc));
             return RFLU_OK;
         }
         void* kargs[] = {&p};
-        if (pipe && p.G >= 2 && p.G <= 64) {
-            if (h->coop_launch) RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_pipe_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), kargs, 0, h->stream));
-            else hipLaunchKernelGGL((panel_pivot_pipe_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
-        } else {
-            if (h->coop_launch && p.G > 1) RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), kargs, 0, h->stream));
-            else hipLaunchKernelGGL((panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
-        }
+        if (h->coop_launch && p.G > 1) RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), kargs, 0, h->stream));
+        else hipLaunchKernelGGL((panel_pivot_kernel<T, 1>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
     } else {
         hipLaunchKernelGGL((panel_nopivot_top_kernel<T>), dim3(1), dim3(NPT_THREADS), 0, h->stream, p);
         // inverses: L11 -> this leaf's slot of h->linv (what launch_diag_inv would compute), U11 -> the spare last slot
@@ -1021,32 +561,6 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
     return RFLU_OK;
 }
 
-// Two full leaves [c0, c0+64) and [c0+64, c0+128), pivoted, in one launch (see panel_pivot_pair_kernel).
-template <typename T>
-int launch_panel_pair(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0, int64_t* ipiv)
-{
-    const int64_t rows = m - r0;
-    if (r0 % NB != 0 || rows < 2 * NB || (rows + PANEL_THREADS - 1) / PANEL_THREADS > MAX_PANEL_WGS) {
-        set_error("launch_panel_pair: unsupported geometry m=%lld r0=%lld", (long long)m, (long long)r0);
-        return RFLU_ERR_ARG;
-    }
-    if (h->epoch > 0xfffff000u) {  // tag wrap: wipe the records and restart the epoch counter
-        RFLU_HIP(hipMemsetAsync(h->pscratch, 0, h->pscratch_bytes, h->stream));
-        h->epoch = 1;
-    }
-    PanelArgs<T> p;
-    p.R = R; p.ld = ld; p.m = (int)m; p.r0 = (int)r0; p.c0 = (int)c0; p.w = 2 * NB;
-    p.ipiv = ipiv; p.info = h->info_dev; p.scratch = h->pscratch;
-    p.G = (int)((rows + PANEL_THREADS - 1) / PANEL_THREADS);
-    p.pm_cnt = h->pm_cnt; p.pm_dst = h->pm_dst; p.pm_src = h->pm_src;
-    p.epoch = h->epoch;
-    h->epoch += 2u * NB + 1u;   // 128 step tags + one for the slot exchange
-    ProfScope ps(h, RFLU_K_PANEL, (double)rows * 4.0 * NB * NB);
-    hipLaunchKernelGGL((panel_pivot_pair_kernel<T>), dim3(p.G), dim3(PANEL_THREADS), 0, h->stream, p);
-    RFLU_HIP(hipGetLastError());
-    return RFLU_OK;
-}
-// resident workgroups of this translation unit's cooperative kernels on a device with num_cus CUs (0: query failed)
 template <typename T>
 static int panel_resident_limit_t(int num_cus)
 {
@@ -1057,18 +571,15 @@ static int panel_resident_limit_t(int num_cus)
         worst = std::min(worst, nb * num_cus);
     };
     ask(reinterpret_cast<const void*>(&panel_pivot_kernel<T, 1>));
-    ask(reinterpret_cast<const void*>(&panel_pivot_pipe_kernel<T>));
     return worst;
 }
 // Two translation units compile this file in parallel (build.py): panel.hip itself instantiates the Float64 kernels and
 // holds the non-template functions, panel_f32.hip (#define RFLU_PANEL_F32_TU, #include "panel.hip") the Float32 kernels.
 #ifdef RFLU_PANEL_F32_TU
-template int launch_panel_pair<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t*);
 template int launch_panel<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 int panel_resident_limit_f32(int num_cus) { return panel_resident_limit_t<float>(num_cus); }
 #else
 int panel_resident_limit_f64(int num_cus) { return panel_resident_limit_t<double>(num_cus); }
-template int launch_panel_pair<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t*);
 template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t*, int);
 
 int panel_resident_limit(int num_cus)

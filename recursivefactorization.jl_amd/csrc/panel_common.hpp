@@ -507,6 +507,10 @@ __device__ __forceinline__ void barrier_lds_only()
 template <typename T>
 int launch_panel_local(Handle* h, const PanelArgs<T>& p, int stride, int sel, int want_xcc, int local);
 
+// panel_single.hip: a leaf of at most 512 rows in one workgroup (no cross-workgroup records at all)
+template <typename T>
+int launch_panel_single(Handle* h, const PanelArgs<T>& p);
+
 int panel_resident_limit_f64(int num_cus);
 int panel_resident_limit_f32(int num_cus);
 int panel_local_resident_limit_f64(int num_cus);

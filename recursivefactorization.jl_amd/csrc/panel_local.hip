@@ -31,6 +31,9 @@ struct LocalArgs {
     int stride;     // !LOCAL: participants are the blocks with blockIdx % stride == sel
     int sel;
     int want_xcc;   // LOCAL: participants are the blocks running on this XCC
+    int poll_delay; // !LOCAL: clocks between a workgroup's header publish and its poll round (first step; then adapted)
+    int poll_adapt; // !LOCAL: adapt the delay step by step (x_w0_exchange)
+    int grid_g;     // participants actually launched (== p.G except under fault injection)
 };
 
 __device__ __forceinline__ unsigned hw_xcc_id()
@@ -87,29 +90,43 @@ struct IKey<float> {
 // covers the two wait states between a VALU write and a DPP read of the same register)
 __device__ __forceinline__ unsigned wave_max_b(unsigned v)
 {
-    asm volatile(
-        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1" : "+v"(v));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_b(unsigned v)
 {
-    asm volatile(
-        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1" : "+v"(v));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// the same over lanes 0..7 only (the <= 8 wave records of a workgroup): three stages, result in lanes 0..7
+__device__ __forceinline__ unsigned wave_max8_b(unsigned v)
+{
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1" : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+}
+__device__ __forceinline__ unsigned wave_min8_b(unsigned v)
+{
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1" : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0);
 }
 
 // Every lane passes (hi, lo, pos); pos == POS_NONE marks a lane without a candidate (its hi / lo must be 0).
@@ -117,10 +134,11 @@ __device__ __forceinline__ unsigned wave_min_b(unsigned v)
 // holds it (0 if none).
 // The common case needs ONE reduction: the high words (sign-free exponent + 20 mantissa bits for Float64) of two rows of a
 // wave almost never coincide at the maximum; only then the low words and, for exact ties, the positions are reduced too.
-template <bool TWO>
+// EIGHT: only lanes 0..7 carry entries (the others pass hi = lo = 0, pos = POS_NONE): three DPP stages instead of six.
+template <bool TWO, bool EIGHT = false>
 __device__ __forceinline__ int wave_argmax_i(unsigned& hi, unsigned& lo, unsigned& pos)
 {
-    const unsigned mh = wave_max_b(hi);
+    const unsigned mh = EIGHT ? wave_max8_b(hi) : wave_max_b(hi);
     bool hit = (hi == mh) && (pos != POS_NONE);
     u64 mask = __ballot(hit);
     unsigned p = POS_NONE, ml = 0u;
@@ -128,12 +146,12 @@ __device__ __forceinline__ int wave_argmax_i(unsigned& hi, unsigned& lo, unsigne
     if (mask != 0) {
         if (__popcll(mask) != 1) {
             if (TWO) {
-                ml = wave_max_b(hit ? lo : 0u);
+                ml = EIGHT ? wave_max8_b(hit ? lo : 0u) : wave_max_b(hit ? lo : 0u);
                 hit = hit && (lo == ml);
                 mask = __ballot(hit);
             }
             if (__popcll(mask) != 1) {   // exact ties: the lowest position among the lanes holding the maximum
-                p = wave_min_b(hit ? pos : POS_NONE);
+                p = EIGHT ? wave_min8_b(hit ? pos : POS_NONE) : wave_min_b(hit ? pos : POS_NONE);
                 mask = __ballot(hit && pos == p);
             }
         }
@@ -228,12 +246,20 @@ struct Hdr4<float> {
 };
 
 template <typename T>
-struct XHand {          // what wave 0 hands to the other waves at barrier A(c)
-    T scale;            // 1 / pivot (1 when the pivot is exactly zero)
+struct alignas(16) XHand {   // what the communication wave hands to the row waves at barrier A(c): read as a whole right
+    T scale;            // after the barrier (one LDS round trip for everything).  1 / pivot (1 when the pivot is exactly zero)
     T wu;               // u_{c,c+1}
-    T p1, p2;           // P_{c-1}[c+1], P_{c-1}[c+2]: what the two chain entries still miss (one LDS round trip for all)
-    unsigned win;       // the pivot's row position (POS_NONE: no candidate anywhere)
+    T p1, p2;           // P_{c-1}[c+1], P_{c-1}[c+2]: what the two chain entries still miss
+    unsigned win;       // the pivot's row position (POS_NONE: no candidate anywhere, POS_DEAD: a peer timed out)
     unsigned cpos;      // position of THIS workgroup's candidate for column c (its owner publishes Rw(c))
+    unsigned pad[sizeof(T) == 8 ? 2 : 2];
+};
+
+template <typename T>
+struct alignas(16) XRec {      // a wave's candidate for column c+1: three 16-byte LDS accesses for the lane that leaves it
+    unsigned hi, lo, pos, pad;
+    T a1, a2;                  // a_{c+1} (complete), a_{c+2} (misses elimination c)
+    T l, pad2;                 // l_c of that row
 };
 
 template <typename T>
@@ -241,19 +267,14 @@ struct XLds {
     T prow[2][NB];             // P_c by parity of c (entries j >= c+2)
     T crow[NB];                // staging of the candidate row for the coalesced publish
     XHand<T> hand[2];          // by parity of c
-    T ra1[PANEL_WAVES];        // per-wave records of the search for column c+1
-    T ra2[PANEL_WAVES];
-    T rl[PANEL_WAVES];
-    unsigned rhi[PANEL_WAVES];
-    unsigned rlo[PANEL_WAVES];
-    unsigned rpos[PANEL_WAVES];
+    XRec<T> rec[PANEL_WAVES];  // per-wave records of the search for column c+1
     T w0_lh[2];                // wave 0: l^H of the winner of column c (finishes P_c), by parity of c
     int w0_wl[2];              // wave 0: workgroup of the winner of column c
     int rows[NB];
 };
 
-// All waves, between the bookkeeping of column c and barrier B(c): search of column c+1 inside the wave; lane 0 leaves the
-// wave's record {key, position, a_{c+1}, a_{c+2}, l_c of the winning lane}.
+// All waves, between the bookkeeping of column c and barrier B(c): search of column c+1 inside the wave; the winning lane
+// leaves the wave's record {key, position, a_{c+1}, a_{c+2}, l_c}.
 template <typename T, int PW>
 __device__ __forceinline__ void x_record(XLds<T>* sh, int tid, T a1, T a2, T l, unsigned pos, bool act)
 {
@@ -264,18 +285,19 @@ __device__ __forceinline__ void x_record(XLds<T>* sh, int tid, T a1, T a2, T l, 
         unsigned mh = hi, ml = lo;
         const int wl = wave_argmax_i<IKey<T>::TWO>(mh, ml, p);
         if (lane == wl) {   // the winning lane leaves the record itself (lane 0 an empty one if the wave has no candidate)
-            sh->rhi[wave] = mh;
-            sh->rlo[wave] = ml;
-            sh->rpos[wave] = p;
-            sh->ra1[wave] = a1;
-            sh->ra2[wave] = a2;
-            sh->rl[wave] = l;
+            XRec<T>* r = &sh->rec[wave];
+            r->hi = mh;
+            r->lo = ml;
+            r->pos = p;
+            r->a1 = a1;
+            r->a2 = a2;
+            r->l = l;
         }
     }
     barrier_lds_only();   // B
 }
 
-// Communication wave after barrier B(c): the workgroup's candidate for column c+1 from the 8 wave records; its header leaves at once.
+// Communication wave after barrier B(c): the workgroup's candidate for column c+1 from the PW wave records; its header leaves at once.
 template <typename T, int AUX, int PW>
 __device__ __forceinline__ void x_w0_publish(XLds<T>* sh, u64* scratch, unsigned epoch, int c1, int g, int lane)
 {
@@ -285,9 +307,12 @@ __device__ __forceinline__ void x_w0_publish(XLds<T>* sh, u64* scratch, unsigned
     g = uni(g);
     const int r = lane & (PW - 1);
     const bool has = lane < PW;   // lanes 0..PW-1 hold the wave records
-    unsigned hi = has ? sh->rhi[r] : 0u, lo = has ? sh->rlo[r] : 0u, cp = has ? sh->rpos[r] : POS_NONE;
-    const T a1 = sh->ra1[r], a2 = sh->ra2[r], l = sh->rl[r];
-    const int wl = wave_argmax_i<IKey<T>::TWO>(hi, lo, cp);
+    const XRec<T>* rc = &sh->rec[r];
+    unsigned hi = rc->hi, lo = rc->lo, cp = rc->pos;
+    const T a1 = rc->a1, a2 = rc->a2, l = rc->l;
+    if (!has) { hi = 0u; lo = 0u; cp = POS_NONE; }
+    const int wl = (PW == 1) ? 0 : wave_argmax_i<IKey<T>::TWO, true>(hi, lo, cp);
+    if (PW == 1) cp = (unsigned)__builtin_amdgcn_readlane((int)cp, 0);
     if (lane == wl)   // the lane that holds the winning record (an empty header if there is no candidate: cp == POS_NONE)
         Hdr4<T>::template store<AUX>(scratch_rsrc(scratch), (unsigned)(c1 & 1) * PS_BUF_BYTES + (unsigned)g * PS_HDR_BYTES,
                                      epoch + (unsigned)c1, cp, a1, a2, l);
@@ -295,14 +320,22 @@ __device__ __forceinline__ void x_w0_publish(XLds<T>* sh, u64* scratch, unsigned
     if (c1 >= 1) RFLU_STAMP(scratch, c1 - 1, 6, g, lane);
 }
 
-// Communication wave before barrier A(c1): finish P_c (c = c1-1) from the winner's row record, poll the G headers of column c1,
-// reduce, complete u_{c1,c1+1}, divide, hand over.
+// Communication wave before barrier A(c1): ONE poll round for the winner's row record of column c = c1-1 (finishes P_c) and the
+// G headers of column c1 -- issued `delay` clocks after this workgroup's own header left, then reduce, complete u_{c1,c1+1},
+// divide, hand over.
+//   The delay: a poll that reaches the memory side before a peer's write-through store has landed comes back stale and costs a
+//   whole second round trip; a pause of about a third of a microsecond between the publish and the first poll lets the
+//   slowest header land first (scripts/probes/xchg.hip: all-to-all of 32 workgroups 1.57 us polling at once, 1.22 us with an
+//   800-clock pause; the round-3 kernel got that pause by accident, from requesting the row record first and the headers only
+//   after it had arrived: two dependent round trips).  It is adapted per workgroup: longer after a stale first poll, slowly
+//   shorter after a fresh one.
 // Returns true when a peer timed out: the hand-over then carries POS_DEAD as the pivot position, which is how the row waves learn of
 // it (one LDS read per step for everything, instead of a separate flag word read -- and waited for -- ahead of the hand-over).
 constexpr unsigned POS_DEAD = 0x7ffffffeu;
+constexpr int POLL_DELAY_MAX = 4000;
 template <typename T>
 __device__ __forceinline__ bool x_w0_exchange(XLds<T>* sh, u64* scratch, int64_t* info, int64_t* ipiv, unsigned epoch, int G,
-                                           int c1, int r0, int g, int lane)
+                                           int c1, int r0, int g, int lane, int& delay)
 {
     scratch = uni(scratch);
     info = uni(info);
@@ -315,40 +348,54 @@ __device__ __forceinline__ bool x_w0_exchange(XLds<T>* sh, u64* scratch, int64_t
     const __amdgpu_buffer_rsrc_t rs = scratch_rsrc(scratch);
     const int c = c1 - 1;
     bool timed_out = false;
-    T pc = T(0);   // P_c[lane]
+    // ---- what this lane asks for: lane x < G the header of workgroup x (column c1); lane j in [c+2, NB) entry j of the row
+    // record of column c's winner
+    int wlc = -1;
+    T lh = T(0);
     if (c >= 0) {
-        const int wlc = uni(sh->w0_wl[c & 1]);
-        const T lh = sh->w0_lh[c & 1];
-        if (wlc >= 0 && lane >= c + 2 && lane < NB) {
-            const unsigned roff = (unsigned)(c & 1) * PS_BUF_BYTES + PS_HDR_REGION + (unsigned)wlc * PS_ROW_BYTES +
-                                  (unsigned)lane * PS_VAL_BYTES;
-            T xv = T(0);
-            int spins = 0;
-            for (;;) {
-                asm volatile("" ::: "memory");  // plain buffer intrinsics: keep the load inside the loop
-                if (Gran<T>::load(rs, roff, epoch + (unsigned)c, xv)) break;
-                if (++spins > SPIN_LIMIT) { timed_out = true; break; }
-            }
-            // entries j >= c+3 still miss elimination c-1 of the (then) candidate row
-            if (c >= 1 && lane >= c + 3) xv -= lh * sh->prow[(c - 1) & 1][lane];
-            pc = xv;
-            sh->prow[c & 1][lane] = xv;
-        }
+        wlc = uni(sh->w0_wl[c & 1]);
+        lh = sh->w0_lh[c & 1];
     }
-    // ---- the headers of column c1: lane x = workgroup x
+    const bool want_h = lane < G;
+    const bool want_r = c >= 0 && wlc >= 0 && lane >= c + 2 && lane < NB;
+    const unsigned hoff = (unsigned)(c1 & 1) * PS_BUF_BYTES + (unsigned)(want_h ? lane : 0) * PS_HDR_BYTES;
+    const unsigned roff = (unsigned)(c & 1) * PS_BUF_BYTES + PS_HDR_REGION + (unsigned)(wlc >= 0 ? wlc : 0) * PS_ROW_BYTES +
+                          (unsigned)lane * PS_VAL_BYTES;
+    if (delay > 0) {
+        const long long t0 = clock64();
+        while (clock64() - t0 < delay) __builtin_amdgcn_s_sleep(1);
+    }
     unsigned xp = POS_NONE;
-    T xa = T(0), xa1 = T(0), xl = T(0);
-    if (lane < G) {
-        const unsigned hoff = (unsigned)(c1 & 1) * PS_BUF_BYTES + (unsigned)lane * PS_HDR_BYTES;
-        int spins = 0;
-        for (;;) {
-            asm volatile("" ::: "memory");
-            if (Hdr4<T>::load(rs, hoff, epoch + (unsigned)c1, xp, xa, xa1, xl)) break;
-            if (++spins > SPIN_LIMIT) { timed_out = true; xp = POS_NONE; break; }
-        }
+    T xa = T(0), xa1 = T(0), xl = T(0), xv = T(0);
+    bool ok_h = !want_h, ok_r = !want_r;
+    int spins = 0;
+    bool first = true, stale_first = false;
+    for (;;) {
+        asm volatile("" ::: "memory");  // plain buffer intrinsics: keep the loads inside the loop
+        bool got_h = ok_h, got_r = ok_r;
+        if (!ok_h) got_h = Hdr4<T>::load(rs, hoff, epoch + (unsigned)c1, xp, xa, xa1, xl);
+        if (!ok_r) got_r = Gran<T>::load(rs, roff, epoch + (unsigned)c, xv);
+        ok_h = got_h;
+        ok_r = got_r;
+        if (!__any(!ok_h || !ok_r)) break;
+        if (first) stale_first = true;
+        first = false;
+        if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+    }
+    delay = stale_first ? min(delay + 64, POLL_DELAY_MAX) : max(delay - 8, 0);
+    if (!ok_h) xp = POS_NONE;
+    T pc = T(0);   // P_c[lane]
+    if (want_r) {
+        // entries j >= c+3 still miss elimination c-1 of the (then) candidate row
+        if (c >= 1 && lane >= c + 3) xv -= lh * sh->prow[(c - 1) & 1][lane];
+        pc = xv;
+        sh->prow[c & 1][lane] = xv;
     }
     unsigned hi, lo, gp = xp;
     IKey<T>::split(xa, xp != POS_NONE, hi, lo);
+    // every lane divides for ITS header while the reduction runs (independent instruction streams: the quotient's ~12 dependent
+    // operations fill the wait states of the DPP chain); the winner's quotient is picked afterwards -- the same IEEE quotient
+    const T xinv = (xa != T(0)) ? T(1) / xa : T(1);
     const int wl = wave_argmax_i<IKey<T>::TWO>(hi, lo, gp);   // the winner's lane is its workgroup index
     const T ga = readlane_val(xa, wl), ga1 = readlane_val(xa1, wl), gl = readlane_val(xl, wl);
     T gu = ga1;
@@ -358,7 +405,7 @@ __device__ __forceinline__ bool x_w0_exchange(XLds<T>* sh, u64* scratch, int64_t
         gp = POS_DEAD;
         if (lane == 0) __hip_atomic_fetch_or((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const T sc = (ga != T(0)) ? T(1) / ga : T(1);   // once per workgroup
+    const T sc = readlane_val(xinv, wl);   // 1 / pivot (1 when the pivot is exactly zero or there is no candidate)
     const T p1 = readlane_val(pc, (c1 + 1) & 63), p2 = readlane_val(pc, (c1 + 2) & 63);   // P_c[c1+1], P_c[c1+2]
     if (lane == 0) {
         XHand<T>* h = &sh->hand[c1 & 1];
@@ -401,11 +448,12 @@ struct XState {
 };
 
 // Step C >= 0: column C.  C == -1 is the prologue: records of column 0, H(0), first exchange.
-template <typename T, int C, int AUX, int PW>
+// FULL: the leaf has all NB columns -- no run-time column tests between the barriers.
+template <typename T, int C, int AUX, int PW, bool FULL>
 __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a)[NB], T& lprev, XState& st, PermState& perm,
                                        int g, int tid)
 {
-    if (C >= p.w || st.dead) return;
+    if ((!FULL && C >= p.w) || st.dead) return;
     const int lane = tid & 63, wave = tid >> 6;
     bool owner = false;
     T l = T(0);
@@ -413,31 +461,34 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
     unsigned win_c = POS_NONE;
     if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 0, g, tid);
     if constexpr (C >= 0) {
-        const XHand<T> h = sh->hand[C & 1];
-        if (h.win == POS_DEAD) { st.dead = true; return; }
-        owner = st.pos == h.cpos && st.pos != POS_NONE;
+        // the whole hand-over in one LDS round trip, requested before anything is tested
+        const volatile XHand<T>* hv = &sh->hand[C & 1];
+        const T h_scale = hv->scale, h_wu = hv->wu, h_p1 = hv->p1, h_p2 = hv->p2;
+        const unsigned h_win = hv->win, h_cpos = hv->cpos;
+        if (h_win == POS_DEAD) { st.dead = true; return; }
+        owner = st.pos == h_cpos && st.pos != POS_NONE;
         if constexpr (C >= 1) {
             if (st.updprev) {   // elimination C-1 on the two entries the next record needs
-                if constexpr (C + 1 < NB) a[C + 1] -= lprev * h.p1;
-                if constexpr (C + 2 < NB) a[C + 2] -= lprev * h.p2;
+                if constexpr (C + 1 < NB) a[C + 1] -= lprev * h_p1;
+                if constexpr (C + 2 < NB) a[C + 2] -= lprev * h_p2;
             }
         }
-        if (h.win != POS_NONE && st.act) {
-            const unsigned kpos = (unsigned)(p.r0 + C);
-            if (st.pos == h.win) {
-                st.pos = kpos;      // pivot row: final position r0+C, no further updates
-                st.act = false;
-            } else {
-                if (st.pos == kpos) st.pos = h.win;   // displaced row takes the pivot's old position
-                upd = true;
-                l = a[C] * h.scale;   // reciprocal-multiply (src/lu.jl:317-320); scale == 1 after a zero pivot
-                a[C] = l;
-                if constexpr (C + 1 < NB) a[C + 1] -= l * h.wu;
-            }
+        const unsigned kpos = (unsigned)(p.r0 + C);
+        const bool is_piv = st.act && st.pos == h_win;          // h_win != POS_NONE whenever an active row matches it
+        upd = st.act && !is_piv && h_win != POS_NONE;
+        if (upd) {
+            if (st.pos == kpos) st.pos = h_win;   // displaced row takes the pivot's old position
+            l = a[C] * h_scale;                   // reciprocal-multiply (src/lu.jl:317-320); scale == 1 after a zero pivot
+            a[C] = l;
+            if constexpr (C + 1 < NB) a[C + 1] -= l * h_wu;
         }
-        win_c = h.win;
+        if (is_piv) {
+            st.pos = kpos;      // pivot row: final position r0+C, no further updates
+            st.act = false;
+        }
+        win_c = h_win;
     }
-    const bool more = C + 1 < p.w;   // workgroup-uniform
+    const bool more = FULL || C + 1 < p.w;   // workgroup-uniform
     if constexpr (C + 1 < NB) {
         if (more) {
             T a2 = T(0);
@@ -448,18 +499,18 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
             if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 3, g, tid);
         }
     }
-    // interchange bookkeeping of column C (one wave of workgroup 0): AFTER barrier B, next to the exchange -- before it, that
-    // wave reached the barrier ~40 instructions after everybody else, every step, and every workgroup waits for the slowest one
-    if constexpr (C >= 0) {
-        if (g == 0 && wave == PW - 1 && win_c != POS_NONE)
-            perm_state_step(perm, p.r0, C, __builtin_amdgcn_readfirstlane((int)win_c), lane);
-    }
     if constexpr (C >= 0 && C + 2 < NB) {
         if (owner) {   // Rw(C): a[C+2] has elimination C-1, the rest C-2 (the deferred loop below has not run yet)
 #pragma unroll
             for (int j = C + 2; j < NB; ++j) sh->crow[j] = a[j];
         }
         if (__ballot(owner) != 0) x_publish_row<T, AUX>(sh, p.scratch, p.epoch, C, g, lane);
+    }
+    // interchange bookkeeping of column C (one wave of workgroup 0): AFTER barrier B, next to the exchange -- before it, that
+    // wave reached the barrier ~40 instructions after everybody else, every step, and every workgroup waits for the slowest one
+    if constexpr (C >= 0) {
+        if (g == 0 && wave == PW - 1 && win_c != POS_NONE)
+            perm_state_step(perm, p.r0, C, __builtin_amdgcn_readfirstlane((int)win_c), lane);
     }
     if constexpr (C >= 1 && C + 3 < NB) {
         if (st.updprev) {   // the rest of elimination C-1
@@ -479,21 +530,22 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
     }
 }
 
-template <typename T, int C0, int C1, int AUX, int PW>
+template <typename T, int C0, int C1, int AUX, int PW, bool FULL>
 struct XSteps {
     static __device__ __forceinline__ void run(const PanelArgs<T>& p, XLds<T>* sh, T (&a)[NB], T& lprev, XState& st,
                                                PermState& perm, int g, int tid)
     {
         if constexpr (C0 < C1) {
-            x_step<T, C0, AUX, PW>(p, sh, a, lprev, st, perm, g, tid);
-            XSteps<T, C0 + 1, C1, AUX, PW>::run(p, sh, a, lprev, st, perm, g, tid);
+            x_step<T, C0, AUX, PW, FULL>(p, sh, a, lprev, st, perm, g, tid);
+            XSteps<T, C0 + 1, C1, AUX, PW, FULL>::run(p, sh, a, lprev, st, perm, g, tid);
         }
     }
 };
 
 // PW = row waves per workgroup: 8 (512 rows, two row waves per SIMD) for tall panels; 4 (256 rows, ONE row wave per SIMD: the
 // dependent instruction chain between the barriers runs without a second wave sharing the issue slots) while the panel's
-// rows still fit 32 such workgroups
+// rows still fit 32 such workgroups.  Full leaves only (w == NB; launch_panel sends a narrower last leaf to the kernels of
+// panel.hip / panel_single.hip): the 64 steps are straight-line code without run-time column tests.
 template <typename T, bool LOCAL, int PW>
 __global__ void __launch_bounds__(PW * 64 + 64) panel_pivot_local_kernel(LocalArgs<T> la)
 {
@@ -519,23 +571,29 @@ __global__ void __launch_bounds__(PW * 64 + 64) panel_pivot_local_kernel(LocalAr
     st.dead = false;
     if (tid == 0) sh->w0_wl[0] = sh->w0_wl[1] = -1;
     T a[NB];
-    load_row_direct<T>(p.R, p.ld, row, st.act, p.c0, p.w, a);
+    load_row_direct<T>(p.R, p.ld, row, st.act, p.c0, NB, a);
+    // the rows are in registers before the first step: a real s_waitcnt (one the compiler's wait-count pass sees), so that no
+    // conservative vmcnt(0) -- a wait for the acknowledgement of the row-record store -- is left at the merges inside the steps
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
     __syncthreads();
     T lprev = T(0);
     PermState perm = perm_state_init(lane);
     if (wave == PW) {
         // communication wave: a run-time loop (no row registers, no static indices), everything inline -- a non-inlined
         // call would wait for the acknowledgement of the stores just issued (s_waitcnt vmcnt(0) at every call boundary)
-        for (int c1 = 0; c1 < p.w; ++c1) {
+        int delay = LOCAL ? 0 : la.poll_delay;   // clocks between the publish and the poll round (adapted, see x_w0_exchange)
+        for (int c1 = 0; c1 < NB; ++c1) {
             barrier_lds_only();   // B(c1 - 1): the wave records of column c1 are in LDS
             x_w0_publish<T, AUX, PW>(sh, p.scratch, p.epoch, c1, g, lane);
-            const bool dead = x_w0_exchange<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, c1, p.r0, g, lane);
+            int d = delay;
+            const bool dead = x_w0_exchange<T>(sh, p.scratch, p.info, p.ipiv, p.epoch, p.G, c1, p.r0, g, lane, d);
+            if (!LOCAL && la.poll_adapt) delay = d;
             barrier_lds_only();   // A(c1)
             if (dead) break;
         }
     } else {
-        XSteps<T, -1, NB, AUX, PW>::run(p, sh, a, lprev, st, perm, g, tid);
-        store_row_direct<T>(p.R, p.ld, st.pos, p.c0, p.w, a);
+        XSteps<T, -1, NB, AUX, PW, true>::run(p, sh, a, lprev, st, perm, g, tid);
+        store_row_direct<T>(p.R, p.ld, st.pos, p.c0, NB, a);
     }
     __syncthreads();
     if (g == 0 && wave == PW - 1) {
@@ -545,22 +603,97 @@ __global__ void __launch_bounds__(PW * 64 + 64) panel_pivot_local_kernel(LocalAr
     }
 }
 
+// ---- host side.  Four translation units (parallel compile of the 64-step kernels): {Float64, Float32} x {any placement,
+// XCD-local}; each holds the launches of its four workgroup sizes (launch_panel_local_variant), the Float64 / any-placement
+// one also the choice between them.
+#if defined(RFLU_PL_F32)
+typedef float pl_t;
+#else
+typedef double pl_t;
+#endif
+#if defined(RFLU_PL_XCD)
+constexpr bool PL_LOCAL = true;
+#else
+constexpr bool PL_LOCAL = false;
+#endif
+
+template <typename T, bool LOCAL>
+int launch_panel_local_variant(Handle* h, const LocalArgs<T>& la, int rpw, int ballast);
+template <typename T, bool LOCAL>
+int panel_local_resident_limit_variant(int num_cus);
+
+template <>
+int launch_panel_local_variant<pl_t, PL_LOCAL>(Handle* h, const LocalArgs<pl_t>& la, int rpw, int ballast)
+{
+    typedef pl_t T;
+    constexpr bool LOCAL = PL_LOCAL;
+    const dim3 grid((unsigned)(la.grid_g * la.stride));
+    if (h->coop_launch && !LOCAL) {   // launch-time residency check by the runtime (opt-in: +15-19 us per launch)
+        LocalArgs<T> lc = la;
+        void* kargs[] = {&lc};
+        RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, LOCAL, 8>), grid,
+                                            dim3(8 * 64 + 64), kargs, 0, h->stream));
+        return RFLU_OK;
+    }
+    if (rpw <= 128) {
+        // LDS ballast: a two- or three-wave workgroup fits next to the update GEMM's workgroups on a shared CU and is then
+        // slowed by them (N=4096: 13.3 ms without, 12.7 ms with); asking for more LDS than a CU with a GEMM workgroup (70 KB
+        // each) has left sends it to an empty CU -- one of those the update stream's mask keeps free.
+        // (the XCD-local variants too: without it N=4096 11.12-11.15 ms, with it 10.74-10.82)
+        bool& attr_set = h->panel_attr_set[LOCAL ? 1 : 0][sizeof(T) == 8 ? 0 : 1][rpw == 64 ? 0 : 1];   // per handle = per device
+        const void* fn = rpw == 64 ? reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, LOCAL, 1>)
+                                   : reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, LOCAL, 2>);
+        if (!attr_set && ballast > 0) {
+            RFLU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ballast));
+            attr_set = true;
+        }
+        if (rpw == 64) hipLaunchKernelGGL((panel_pivot_local_kernel<T, LOCAL, 1>), grid, dim3(1 * 64 + 64), (size_t)ballast, h->stream, la);
+        else hipLaunchKernelGGL((panel_pivot_local_kernel<T, LOCAL, 2>), grid, dim3(2 * 64 + 64), (size_t)ballast, h->stream, la);
+    } else if (rpw == 256) {
+        hipLaunchKernelGGL((panel_pivot_local_kernel<T, LOCAL, 4>), grid, dim3(4 * 64 + 64), 0, h->stream, la);
+    } else {
+        hipLaunchKernelGGL((panel_pivot_local_kernel<T, LOCAL, 8>), grid, dim3(8 * 64 + 64), 0, h->stream, la);
+    }
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+template <>
+int panel_local_resident_limit_variant<pl_t, PL_LOCAL>(int num_cus)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&panel_pivot_local_kernel<pl_t, PL_LOCAL, 8>),
+                                                     8 * 64 + 64, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        nb = 0;
+    }
+    return nb * num_cus;
+}
+
+#if !defined(RFLU_PL_XCD)
+// the XCD-local variants live in panel_local_xcd*.hip
+template <>
+int launch_panel_local_variant<pl_t, true>(Handle* h, const LocalArgs<pl_t>& la, int rpw, int ballast);
+template <>
+int panel_local_resident_limit_variant<pl_t, true>(int num_cus);
+
+#if !defined(RFLU_PL_F32)
 // Rows per workgroup of a pivoted leaf of `rows` rows.  The fewer row waves a workgroup has, the cheaper its per-column
-// argmax / barrier: 2.44 (64 rows), 2.55 (128), 2.72 (256) and 2.95 us per column (512) alone on the GPU
-// (scripts/panel_bench.py).  One polling wave reads at most 64 headers and the lookahead schedule keeps 32 or 64 CUs free, so a
-// panel takes the smallest workgroup that keeps it at <= RFLU_PANEL_MAXG workgroups; RFLU_PANEL_PW=1|2|4|8 sets a floor.
-#ifndef RFLU_PANEL_F32_TU
+// argmax / barrier (scripts/panel_bench.py).  One polling wave reads at most 64 headers and the lookahead schedule keeps 32 or
+// 64 CUs free, so a panel takes the smallest workgroup that keeps it at <= h->tune.panel_maxg workgroups; h->tune.panel_pw
+// (RFLU_PANEL_PW=1|2|4|8) sets a floor.
 int panel_local_rows_per_wg(const Handle* h, int64_t rows)
 {
-    static const int force_pw = [] { const char* e = getenv("RFLU_PANEL_PW"); return e ? atoi(e) : 0; }();
-    static const int max_g = [] { const char* e = getenv("RFLU_PANEL_MAXG"); return e ? atoi(e) : 32; }();
     if (h->coop_launch) return 512;
-    const int floor_pw = force_pw > 0 ? force_pw : 1;
+    const int floor_pw = h->tune.panel_pw > 0 ? h->tune.panel_pw : 1;
+    const int max_g = h->tune.panel_maxg;
     if (floor_pw <= 1 && (rows + 63) / 64 <= max_g) return 64;
     if (floor_pw <= 2 && (rows + 127) / 128 <= max_g) return 128;
     if (floor_pw <= 4 && (rows + 255) / 256 <= 32) return 256;
     return 512;
 }
+#else
+int panel_local_rows_per_wg(const Handle* h, int64_t rows);
 #endif
 
 // Launch the leaf on the blocks b with b % stride == sel of a grid of G*stride workgroups.  local != 0: plain-store
@@ -573,6 +706,9 @@ int launch_panel_local(Handle* h, const PanelArgs<T>& p0, int stride, int sel, i
     la.stride = stride;
     la.sel = sel;
     la.want_xcc = want_xcc;
+    la.poll_delay = h->tune.poll_delay;
+    la.poll_adapt = h->tune.poll_adapt;
+    if (p0.w != NB) { set_error("launch_panel_local: full leaves only (w = %d)", p0.w); return RFLU_ERR_ARG; }
     const int64_t rows = (int64_t)p0.m - p0.r0;
     int rpw = local ? (((rows + 255) / 256 <= 32 && !h->coop_launch) ? 256 : 512) : panel_local_rows_per_wg(h, rows);
     // XCD-local: at most 16 participants (the other 7/8 of the launch have to find a home too), so the short workgroups whose
@@ -580,72 +716,32 @@ int launch_panel_local(Handle* h, const PanelArgs<T>& p0, int stride, int sel, i
     if (local && !h->coop_launch) {
         if ((rows + 63) / 64 <= 16) rpw = 64;
         else if ((rows + 127) / 128 <= 16) rpw = 128;
+        else if (h->tune.panel_local_pw8_rows > 0 && rows > h->tune.panel_local_pw8_rows) rpw = 512;
     }
     la.p.G = (int)((rows + rpw - 1) / rpw);
-    const bool pw4 = rpw == 256;
-    const dim3 grid((unsigned)(la.p.G * stride));
-    if (h->coop_launch && stride == 1) {   // launch-time residency check by the runtime (opt-in: +15-19 us per launch)
-        void* kargs[] = {&la};
-        RFLU_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 8>), grid,
-                                            dim3(8 * 64 + 64), kargs, 0, h->stream));
-        return RFLU_OK;
-    }
-    if (rpw <= 128) {
-        // LDS ballast: a two- or three-wave workgroup fits next to the update GEMM's workgroups on a shared CU and is then
-        // slowed by them (N=4096: 13.3 ms without, 12.7 ms with); asking for more LDS than a CU with a GEMM workgroup (70 KB
-        // each) has left sends it to an empty CU -- one of those the update stream's mask keeps free.
-        static const int ballast = [] { const char* e = getenv("RFLU_PANEL_BALLAST"); return e ? atoi(e) : 96 * 1024; }();
-        // (the XCD-local variants too: without it N=4096 11.12-11.15 ms, with it 10.74-10.82)
-        bool& attr_set = h->panel_attr_set[local ? 1 : 0][sizeof(T) == 8 ? 0 : 1][rpw == 64 ? 0 : 1];   // per handle = per device
-        const void* fn = local ? (rpw == 64 ? reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, true, 1>)
-                                            : reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, true, 2>))
-                               : (rpw == 64 ? reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 1>)
-                                            : reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 2>));
-        if (!attr_set && ballast > 0) {
-            RFLU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ballast));
-            attr_set = true;
-        }
-        if (local) {
-            if (rpw == 64) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true, 1>), grid, dim3(1 * 64 + 64), (size_t)ballast, h->stream, la);
-            else hipLaunchKernelGGL((panel_pivot_local_kernel<T, true, 2>), grid, dim3(2 * 64 + 64), (size_t)ballast, h->stream, la);
-        } else {
-            if (rpw == 64) hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 1>), grid, dim3(1 * 64 + 64), (size_t)ballast, h->stream, la);
-            else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 2>), grid, dim3(2 * 64 + 64), (size_t)ballast, h->stream, la);
-        }
-        RFLU_HIP(hipGetLastError());
-        return RFLU_OK;
-    }
-    if (pw4) {
-        if (local) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true, 4>), grid, dim3(4 * 64 + 64), 0, h->stream, la);
-        else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 4>), grid, dim3(4 * 64 + 64), 0, h->stream, la);
-    } else {
-        if (local) hipLaunchKernelGGL((panel_pivot_local_kernel<T, true, 8>), grid, dim3(8 * 64 + 64), 0, h->stream, la);
-        else hipLaunchKernelGGL((panel_pivot_local_kernel<T, false, 8>), grid, dim3(8 * 64 + 64), 0, h->stream, la);
-    }
-    RFLU_HIP(hipGetLastError());
-    return RFLU_OK;
+    la.grid_g = la.p.G;
+    // fault injection (tests): this launch polls for one participant more than it has -- the bounded spins end it with the timeout flag
+    if (h->tune.debug_ghost_leaf >= 0 && h->coop_leaf_seq == h->tune.debug_ghost_leaf && la.p.G < 63) la.p.G += 1;
+    h->coop_leaf_seq++;
+    const int ballast = h->tune.panel_ballast;
+    if (local && !h->coop_launch) return launch_panel_local_variant<T, true>(h, la, rpw, ballast);
+    la.stride = 1;
+    la.sel = 0;
+    return launch_panel_local_variant<T, false>(h, la, rpw, ballast);
 }
 
-template <typename T>
-static int panel_local_resident_limit_t(int num_cus)
+template int launch_panel_local<pl_t>(Handle*, const PanelArgs<pl_t>&, int, int, int, int);
+#if defined(RFLU_PL_F32)
+int panel_local_resident_limit_f32(int num_cus)
 {
-    int worst = 1 << 30;
-    auto ask = [&](const void* fn) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 8 * 64 + 64, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
-        worst = std::min(worst, nb * num_cus);
-    };
-    ask(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, true, 8>));
-    ask(reinterpret_cast<const void*>(&panel_pivot_local_kernel<T, false, 8>));
-    return worst;
+    return std::min(panel_local_resident_limit_variant<float, false>(num_cus), panel_local_resident_limit_variant<float, true>(num_cus));
 }
-
-#ifdef RFLU_PANEL_F32_TU
-template int launch_panel_local<float>(Handle*, const PanelArgs<float>&, int, int, int, int);
-int panel_local_resident_limit_f32(int num_cus) { return panel_local_resident_limit_t<float>(num_cus); }
 #else
-template int launch_panel_local<double>(Handle*, const PanelArgs<double>&, int, int, int, int);
-int panel_local_resident_limit_f64(int num_cus) { return panel_local_resident_limit_t<double>(num_cus); }
+int panel_local_resident_limit_f64(int num_cus)
+{
+    return std::min(panel_local_resident_limit_variant<double, false>(num_cus), panel_local_resident_limit_variant<double, true>(num_cus));
+}
 #endif
+#endif  // !RFLU_PL_XCD
 
 }  // namespace rflu

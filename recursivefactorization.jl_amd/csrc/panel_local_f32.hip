@@ -1,3 +1,3 @@
-// Float32 instantiation of the XCD-local leaf kernel in its own translation unit (parallel compile, see build.py)
-#define RFLU_PANEL_F32_TU
+// Float32, any placement (a translation unit of its own: parallel compile)
+#define RFLU_PL_F32 1
 #include "panel_local.hip"

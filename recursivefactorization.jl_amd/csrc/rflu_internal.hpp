@@ -45,7 +45,66 @@ struct ProfSlot {
     double bytes = 0.0;  // algorithmic (minimum) HBM bytes of the launches
 };
 
+// ---- tuning and debugging variables -----------------------------------------------------------------------------------
+// Every RFLU_* environment variable of the library lives here: read ONCE per handle (rflu_create -> Tune::load_env) -- no
+// getenv on the factorization paths -- and again only when the host asks for it (rflu_reload_tuning; the tests switch
+// variables between calls).  INTEGRATION.md lists them.
+struct Tune {
+    // leaf panel
+    int panel_pw = 0;                  // RFLU_PANEL_PW: floor for the row waves per cooperative workgroup (1|2|4|8)
+    int panel_maxg = 32;               // RFLU_PANEL_MAXG: most workgroups of the short-workgroup leaves
+    int panel_ballast = 96 * 1024;     // RFLU_PANEL_BALLAST: dynamic LDS asked for by the 64- / 128-row workgroups (keeps them off shared CUs)
+    int64_t panel_local_min = 256;     // RFLU_PANEL_LOCAL_MIN
+    int64_t panel_local_rows = -1;     // RFLU_PANEL_LOCAL_ROWS: tallest XCD-local panel (-1: 4096 Float64 / 8192 Float32)
+    int64_t panel_local_pw8_rows = 0;  // RFLU_PANEL_LOCAL_PW8_ROWS: XCD-local panels taller than this use 512-row workgroups (0: never)
+    int poll_delay = 700;              // RFLU_POLL_DELAY: clocks between a workgroup's header publish and its poll round
+    int poll_adapt = 1;                // RFLU_POLL_ADAPT: adapt that delay step by step
+    // kernels
+    int laswp_lpr = 0;                 // RFLU_LASWP_LPR
+    int gemm_flags = 1;                // RFLU_GEMM_FLAGS
+    int skinny_max_k = 128;            // RFLU_SKINNY_MAXK
+    int skinny_wide = 0;               // RFLU_SKINNY_WIDE
+    int64_t gemm_cfirst_below = (int64_t)1 << 40;   // RFLU_GEMM_CFIRST_BELOW
+    int gemm_masked = -1;              // RFLU_GEMM_MASKED: stand-alone rflu_gemm_* calls on the CU-masked stream leaving this many CUs free
+    int64_t ld_pad = 0;                // RFLU_LD_PAD
+    int64_t trsv_max_rhs = 32;         // RFLU_TRSV_MAX_RHS
+    // streams and queues
+    int queue_check = 1;               // RFLU_QUEUE_CHECK
+    int queue_trace = 0;               // RFLU_QUEUE_TRACE
+    // block-column lookahead schedule
+    int split_all = 0;                 // RFLU_SPLIT_ALL
+    double split_share = 0.5;          // RFLU_SPLIT_SHARE
+    double split_scale = 1.0;          // RFLU_SPLIT_SCALE
+    int max_reserve = 64;              // RFLU_MAX_RESERVE
+    int min_reserve = 32;              // RFLU_RESERVE_CUS
+    int64_t confine_rows = (int64_t)1 << 40;   // RFLU_CONFINE_ROWS
+    int64_t merge_rows = -1;           // RFLU_MERGE_ROWS (-1: 8192 Float64, never Float32)
+    // leaf-wise schedule
+    int leafwise = 1;                  // RFLU_LEAFWISE
+    int64_t leafwise_rows = -1;        // RFLU_LEAFWISE_ROWS (-1: 8192 Float64 / 16384 Float32)
+    int swap_su = -1;                  // RFLU_SWAP_SU (-1: by size)
+    int gate_fold = 1;                 // RFLU_GATE_FOLD
+    int gate_trace = 0;                // RFLU_GATE_TRACE
+    int schedule_events = 0;           // RFLU_SCHEDULE=events: cross-stream edges by hipEvents only, no device-side gates (what a
+                                       // counter-collection run needs: rocprofv3 --pmc runs one kernel at a time)
+    int time_enqueue = 0;              // RFLU_TIME_ENQUEUE
+    int tail_overlap = 1;              // RFLU_TAIL_OVERLAP
+    // host-pointer entry
+    int64_t host_early_out = 512;      // RFLU_HOST_EARLY_OUT
+    int host_trace = 0;                // RFLU_HOST_TRACE
+    int host_threads = 8;              // RFLU_HOST_THREADS
+    // multi-GPU
+    int64_t mgpu_big_reserve = 128;    // RFLU_MGPU_BIG_RESERVE
+    int64_t mgpu_tall_rows = -1;       // RFLU_MGPU_TALL_ROWS
+    int mgpu_sync = 0;                 // RFLU_MGPU_SYNC
+    // fault injection (tests): the cooperative leaf launch with this sequence number inside a factorization waits for a
+    // participant that does not exist, runs into its bounded spin and raises the timeout flag (RFLU_ERR_TIMEOUT at the end)
+    int debug_ghost_leaf = -1;         // RFLU_DEBUG_GHOST_LEAF
+    void load_env();                   // driver.cpp
+};
+
 struct Handle {
+    Tune tune;
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -60,6 +119,8 @@ struct Handle {
     bool out_done = false;                     // set by before_sync: the factors are already in the caller's buffer
     std::vector<hipEvent_t> out_events;        // event pool of that path
     void* bounce[2] = {};                      // pinned bounce buffers of that path (one chunk of rows each)
+    void* out_stage = nullptr;                 // device staging of the outgoing chunks (two pieces), so that the input copy stays intact
+    size_t out_stage_bytes = 0;
     size_t bounce_bytes = 0;
     std::vector<hipStream_t> parked_streams;   // masked streams that shared a pipe with a stream in use (validate_queues): kept idle
     long long* qprobe_slots = nullptr;         // device: 4 stamps of the pipe probe
@@ -105,11 +166,13 @@ struct Handle {
     unsigned long long* pscratch = nullptr;
     size_t pscratch_bytes = 0;
     unsigned epoch = 1;          // next unused granule tag
+    int coop_leaf_seq = 0;       // cooperative leaf launches since the start of the current factorization (Tune::debug_ghost_leaf)
     int64_t* info_dev = nullptr; // [0] = info, [1] = panel error flags (bit0 timeout, bit1 XCD placement mismatch)
     // pipelined leaf kernel with a communication wave (panel_local.hip), RFLU_PANEL_LOCAL: 0 = off (the kernels of
     // panel.hip), 2 = on with sc1 records on any placement (default), 1 = all workgroups on XCD panel_xcc with plain-store
     // records through that XCD's L2 (needs that XCD free: experiments only)
     int panel_local = 2;
+    int panel_single = 1;        // RFLU_PANEL_SINGLE: leaves of at most 512 rows in one workgroup, LDS only (panel_single.hip)
     int panel_local_maxg = 64;
     int panel_xcc = 0;
     int trsv_max_wgs = 0;        // same for the cooperative solve kernels (asked on first use)

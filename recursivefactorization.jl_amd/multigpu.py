@@ -25,6 +25,11 @@ class MultiGPU:
         _ffi.check(self.lib.rflu_mgpu_create(ctypes.byref(self.ptr), self.ndev, arr))
         self.fake = bool(self.lib.rflu_mgpu_is_fake(self.ptr))
 
+    @property
+    def collectives(self) -> int:
+        """ncclBroadcast calls enqueued so far (0 in fake mode; see RFLU_MGPU_FORCE_RCCL in include/rflu.h)."""
+        return int(self.lib.rflu_mgpu_collectives(self.ptr))
+
     def close(self):
         if getattr(self, "ptr", None) is not None and self.ptr.value:
             self.lib.rflu_mgpu_destroy(self.ptr)

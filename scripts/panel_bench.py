@@ -1,6 +1,7 @@
-"""Per-column time of one cooperative leaf (m x 64, Float64) for the panel kernel variants, alone on the GPU, and a
-bit-for-bit comparison of their results.  RFLU_PANEL_LOCAL: 0 = pipelined sc1 kernel (panel.hip), 1 = XCD-local kernel
-(panel_local.hip, plain-store records on one XCD), 2 = the same kernel with sc1 records on any placement.
+"""Per-column time of one leaf (m x 64, Float64) for the panel kernel variants, alone on the GPU, and a bit-for-bit
+comparison of their results.  Modes: 0 = the two-trip reference kernel of panel.hip (RFLU_PANEL_LOCAL=0, RFLU_PANEL_SINGLE=0),
+1 = XCD-local cooperative leaf (panel_local.hip, plain-store records on one XCD), 2 = the shipped routing (one-workgroup LDS
+leaf up to 512 rows, cooperative leaf with sc1 records on any placement above), 3 = mode 2 without the one-workgroup leaf.
 usage: python scripts/panel_bench.py [m ...]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,8 @@ dtype = torch.float32 if os.environ.get("PANEL_F32") else torch.float64
 sfx = "f32" if dtype == torch.float32 else "f64"
 ref = {}
 for mode in modes:
-    os.environ["RFLU_PANEL_LOCAL"] = str(mode)
+    os.environ["RFLU_PANEL_LOCAL"] = str({0: 0, 1: 1, 2: 2, 3: 2}[mode])
+    os.environ["RFLU_PANEL_SINGLE"] = "0" if mode in (0, 3) else "1"
     h = _ffi.Handle(0)
     h.set_stream(None)
     for m in sizes:

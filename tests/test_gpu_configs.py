@@ -129,6 +129,73 @@ def test_n16384_float32_and_nopivot_variants(dtype, record_property):
         _free(A, F)
 
 
+def test_headline_n16384_ipiv_equals_cpu_path(record_property):
+    """The north star's bar on the configuration the headline is quoted on: `ipiv` of the N=16384 Float64 factorization equal,
+    entry by entry, to the CPU path's on the same input (src/lu.jl:298-305 picks the pivots; the oracle restates it, threaded
+    as `thread = Val(true)` does, results independent of the thread count) -- and to LAPACK's dgetrf, the comparator of the
+    reference's own tests (test/runtests.jl:11,52).  About a minute of host time on the GPU box."""
+    import os
+    import oracle as O
+    n = 16384
+    O.use_native()
+    O.set_threads(min(64, os.cpu_count() or 1))
+    try:
+        A = O.fill_uniform(n, n, 12)                      # the generator the device fill mirrors bit for bit
+        _, ipo, info_o = O.lu(A)
+    finally:
+        O.set_threads(1)
+    assert info_o == 0
+    dA, F = _factor(n, np.float64, True, 0, seed=12)
+    assert F.info == 0 and rf.last_path() == "hip-lookahead"
+    # same input on both sides: spot-check a strided sample of the device matrix against the host one
+    idx = torch.arange(0, n, 257, device=dA.device)
+    assert np.array_equal(dA[idx][:, idx].cpu().numpy(), A[::257, ::257])
+    ip = F.ipiv.cpu().numpy()
+    assert np.array_equal(ip, ipo), f"first difference at pivot {int(np.argmax(ip != ipo))}"
+    res = matvec_residual(dA, F.factors, F.ipiv)
+    record_property("residual", res)
+    assert res < 1e-12, res
+    try:
+        import scipy.linalg as sla
+        _, piv, info_l = sla.lapack.dgetrf(A, overwrite_a=True)
+        assert info_l == 0
+        assert np.array_equal(ip, piv.astype(np.int64) + 1), "ipiv differs from LAPACK dgetrf"
+    except ImportError:
+        pass
+    _free(dA, F)
+
+
+def test_headline_size_float32_info_and_residual_vs_cpu_path(record_property):
+    """N=16384 Float32 against the CPU path: `info` equal and both residuals inside the reference's bound E = 20 n eps
+    (test/runtests.jl:19-20).  Float32 pivot sequences may fork between two equally valid summation orders from n ~ 1500 on
+    (DESIGN.md section 5), so the number of equal leading pivots is reported, not asserted."""
+    import os
+    import oracle as O
+    n = 16384
+    O.use_native()
+    O.set_threads(min(64, os.cpu_count() or 1))
+    try:
+        A = O.fill_uniform(n, n, 12, np.float32)
+        Fo, ipo, info_o = O.lu(A)
+    finally:
+        O.set_threads(1)
+    dA, F = _factor(n, np.float32, True, 0, seed=12)
+    assert F.info == info_o == 0
+    E = 20 * n * np.finfo(np.float32).eps
+    res = matvec_residual(dA, F.factors, F.ipiv)
+    dFo = torch.from_numpy(np.ascontiguousarray(Fo.T)).to(dA.device).T
+    res_cpu = matvec_residual(dA, dFo, torch.from_numpy(ipo))
+    record_property("residual_gpu", res)
+    record_property("residual_cpu_path", res_cpu)
+    ip = F.ipiv.cpu().numpy()
+    same = int(np.argmax(ip != ipo)) if (ip != ipo).any() else n
+    record_property("equal_leading_pivots", same)
+    print(f"N=16384 Float32: residual GPU {res:.3e}, CPU path {res_cpu:.3e}, equal leading pivots {same} of {n}")
+    assert res < E and res_cpu < E, (res, res_cpu)
+    assert res < 4 * res_cpu + 1e-6
+    _free(dA, F, dFo)
+
+
 @pytest.mark.parametrize("n,bs", [(2048, 128), (3000, 256), (4096, 512), (12288, 512)])
 def test_leafwise_schedule_matches_default(n, bs, monkeypatch):
     """The leaf-wise schedule (driver.cpp: factor_leafwise, the default for panels of at most 8192 rows) applies the same
@@ -140,24 +207,6 @@ def test_leafwise_schedule_matches_default(n, bs, monkeypatch):
     _, G = _factor(n, np.float64, True, bs)
     assert F.info == 0 and G.info == 0
     assert rf.last_path() == "hip-lookahead"
-    assert torch.equal(F.ipiv, G.ipiv)
-    scale = float(F.factors.abs().max())
-    assert float((F.factors - G.factors).abs().max()) <= 1e-10 * scale
-    assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
-
-
-@pytest.mark.parametrize("env", [{"RFLU_DEEP": "1"}, {"RFLU_DEEP": "1", "RFLU_DEEP_KMAX": "4", "RFLU_DEEP_Q": "2", "RFLU_LEAFWISE_ROWS": "2048"},
-                                 {"RFLU_DEEP": "1", "RFLU_DEEP_WIN": "1", "RFLU_DEEP_SCALE": "0.8"}])
-@pytest.mark.parametrize("n,bs", [(4096, 256), (6144, 512), (5000, 256)])
-def test_deep_schedule_matches_default(n, bs, env, monkeypatch):
-    """The round-3 opt-in deep-lookahead schedule (factor_deep: sweeps with per-column state, window stream, K aggregation, also with
-    tall panels factored by the recursion: RFLU_LEAFWISE_ROWS) applies the same eliminations in the same order as the default
-    schedules: identical pivots, factors equal to rounding, residual below the 1e-12 bar."""
-    A, F = _factor(n, np.float64, True, bs)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    _, G = _factor(n, np.float64, True, bs)
-    assert F.info == 0 and G.info == 0
     assert torch.equal(F.ipiv, G.ipiv)
     scale = float(F.factors.abs().max())
     assert float((F.factors - G.factors).abs().max()) <= 1e-10 * scale

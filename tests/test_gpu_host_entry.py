@@ -68,3 +68,27 @@ def test_host_entry_with_a_column_stride_and_reuse():
     refB, ipB, _ = _device_reference(A[:8192 - 512, :8192 - 512], True, None)
     F = rf.lu_(B, None, True, check=False)
     assert np.array_equal(np.asarray(F.factors), refB) and np.array_equal(np.asarray(F.ipiv), ipB)
+
+
+@pytest.mark.parametrize("ghost_leaf", [100, 3])
+def test_failed_factorization_leaves_the_callers_matrix_untouched(ghost_leaf, monkeypatch):
+    """Finished block rows travel home while the rest is factored -- but a panel timeout (or a placement error) is only known at the
+    end.  RFLU_DEBUG_GHOST_LEAF makes one cooperative leaf wait for a participant that does not exist: its bounded spins run out,
+    the call returns RFLU_ERR_TIMEOUT -- and the caller's host matrix must be bit-identical to the input (rows that already went
+    home are taken back from the device copy of the input, which is only overwritten after success), so that a host which falls
+    back to another solver after the error factors the right matrix (the reference's boundary: lu! of a host array,
+    src/lu.jl:116-121)."""
+    n = 8192
+    A = O.fill_uniform(n, n, 91, np.float64)
+    H = np.asfortranarray(A.copy())
+    monkeypatch.setenv("RFLU_DEBUG_GHOST_LEAF", str(ghost_leaf))
+    with pytest.raises(rf.RfluError) as exc:
+        rf.lu_(H, None, True, check=False)
+    assert "timed out" in str(exc.value)
+    assert np.array_equal(H, A), "the caller's matrix was modified by a failed call"
+    monkeypatch.delenv("RFLU_DEBUG_GHOST_LEAF")
+    # the handle is usable afterwards and gives the right answer
+    ref, ipr, infr = _device_reference(A, True, None)
+    F = rf.lu_(H, None, True, check=False)
+    assert F.info == infr == 0
+    assert np.array_equal(np.asarray(F.factors), ref) and np.array_equal(np.asarray(F.ipiv), ipr)

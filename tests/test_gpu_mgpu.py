@@ -121,3 +121,44 @@ def test_baseline_configs_3_4_in_their_layout_full_size(n, k, record_property):
     assert np.array_equal(ipiv, F.ipiv.cpu().numpy()), "k-GPU pivots must equal the 1-GPU pivots"
     del A, F
     torch.cuda.empty_cache()
+
+
+def test_rccl_code_path_executes_with_a_one_rank_communicator():
+    """A box of this pool has ONE GPU, so the collective of the multi-GPU driver (dlopen of librccl.so, ncclCommInitAll, the
+    grouped ncclBroadcast pair of {panel, pivots} per block column on the library's panel stream, ordered against the CU-masked
+    update streams) never runs in fake mode.  RFLU_MGPU_FORCE_RCCL=1 makes a one-device object build a one-rank communicator
+    and broadcast every block column to itself: the same calls, on the same streams, as with k ranks.  In a subprocess: RCCL's
+    runtime state should not leak into the other tests of this process."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+os.environ["RFLU_MGPU_FORCE_RCCL"] = "1"
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import oracle as O
+from recursivefactorization.jl_amd.multigpu import MultiGPU
+n, block = 1536, 256
+mg = MultiGPU([0])
+assert not mg.fake and mg.ndev == 1
+slabs, lds, layout = mg.alloc(n, torch.float64, block, 1)
+mg.fill_uniform(n, slabs, lds, block, 1, seed=12)
+A = O.np_uniform(n, n, 12)
+ipiv, info = mg.getrf(n, slabs, lds, block, 1, pivot=True)
+nblk = (n + block - 1) // block
+assert mg.collectives == 2 * nblk, (mg.collectives, nblk)
+Fo, ipo, info_o = O.lu(A)
+assert info == info_o == 0 and np.array_equal(ipiv, ipo)
+LU = mg.gather(slabs, layout, n)
+mx, fro = O.residual(A, LU, ipiv)
+assert fro < 1e-12, fro
+# a second factorization on the same communicator, Float32
+s32, l32, lay32 = mg.alloc(n, torch.float32, block, 1)
+mg.fill_uniform(n, s32, l32, block, 1, seed=5)
+ip32, info32 = mg.getrf(n, s32, l32, block, 1, pivot=True)
+assert info32 == 0 and mg.collectives == 4 * nblk
+mg.close()
+print("RCCL-ONE-RANK-OK", 4 * nblk)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

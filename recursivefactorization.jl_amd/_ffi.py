@@ -97,6 +97,8 @@ def load() -> ctypes.CDLL:
             pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
+            if not hasattr(lib, name) and os.environ.get("RFLU_LIB"):
+                continue   # an older experiment build named by RFLU_LIB (scripts/r04_ab.sh): entry points added since are simply absent
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

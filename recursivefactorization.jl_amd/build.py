@@ -9,9 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "librflu.so")
-SOURCES = ["gemm.hip", "panel.hip", "panel_f32.hip", "panel_local.hip", "panel_local_f32.hip", "panel_local_xcd.hip", "panel_local_xcd_f32.hip", "panel_single.hip", "panel_single_f32.hip", "trsm.hip", "trsv.hip", "laswp.hip", "butterfly.hip", "driver.cpp"]
-HEADERS = ["rflu_internal.hpp", "panel_common.hpp", "trsm_row.hpp", os.path.join("..", "..", "include", "rflu.h")]
-EXTRA_DEPS = {"panel_f32.hip": ["panel.hip"], "panel_local_f32.hip": ["panel_local.hip"], "panel_local_xcd.hip": ["panel_local.hip"], "panel_local_xcd_f32.hip": ["panel_local.hip"], "panel_single_f32.hip": ["panel_single.hip"]}  # a source that #includes another source
+SOURCES = ["gemm.hip", "panel.hip", "panel_f32.hip", "panel_local.hip", "panel_local_f32.hip", "panel_local_xcd.hip", "panel_local_xcd_f32.hip", "panel_single.hip", "panel_single_f32.hip", "panel_blocked.hip", "panel_blocked_f32.hip", "trsm.hip", "trsv.hip", "laswp.hip", "butterfly.hip", "driver.cpp"]
+HEADERS = ["rflu_internal.hpp", "panel_common.hpp", "panel_xchg.hpp", "trsm_row.hpp", os.path.join("..", "..", "include", "rflu.h")]
+EXTRA_DEPS = {"panel_f32.hip": ["panel.hip"], "panel_local_f32.hip": ["panel_local.hip"], "panel_local_xcd.hip": ["panel_local.hip"], "panel_local_xcd_f32.hip": ["panel_local.hip"], "panel_single_f32.hip": ["panel_single.hip"], "panel_blocked_f32.hip": ["panel_blocked.hip"]}  # a source that #includes another source
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
 
 

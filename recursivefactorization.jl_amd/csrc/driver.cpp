@@ -98,12 +98,14 @@ static void load_handle_env(Handle* h)
     h->coop_launch = false;
     h->panel_local = 2;
     h->panel_single = 1;
+    h->panel_blocked = 0;
     h->panel_local_maxg = 64;
     int v = 0;
     env_get("RFLU_COOP_LAUNCH", v);
     h->coop_launch = v != 0;
     env_get("RFLU_PANEL_LOCAL", h->panel_local);
     env_get("RFLU_PANEL_SINGLE", h->panel_single);
+    env_get("RFLU_PANEL_BLOCKED", h->panel_blocked);
     if (h->panel_local == 1) h->panel_local_maxg = 32;   // one XCD has 32 CUs
     env_get("RFLU_PANEL_LOCAL_MAXG", h->panel_local_maxg);
 }
@@ -369,11 +371,9 @@ struct Fact {
 };
 
 // workgroups of the cooperative leaf on `rows` rows (the CUs a schedule has to keep free for it)
-static int64_t panel_wgs(const Handle* h, int64_t rows, int pivot)
+static int64_t panel_wgs(const Handle* h, int64_t rows, int pivot, size_t esize)
 {
-    rows = std::max<int64_t>(rows, 1);
-    const int64_t rpw = (pivot && h->panel_local > 0) ? panel_local_rows_per_wg(h, rows) : PANEL_THREADS;
-    return (rows + rpw - 1) / rpw;
+    return panel_plan_wgs(h, rows, esize, pivot);
 }
 
 static int get_event(Handle* h, size_t idx, hipEvent_t* ev)
@@ -615,7 +615,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     for (int64_t b = 0; b < std::min(nblk, b_end); ++b) {
         const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
         {
-            const int64_t g_b = panel_wgs(h, m - j0, f.pivot);
+            const int64_t g_b = panel_wgs(h, m - j0, f.pivot, sizeof(T));
             const int res_b = std::max<int>(min_reserve, int((std::max<int64_t>(g_b, 1) + 31) / 32 * 32));
             hipStream_t to = userS;
             if (b > 0 && prev_overlapped && m - j0 >= confine_rows && res_b == 32)   // taller panels: restB needs the whole GPU
@@ -633,7 +633,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         RFLU_TRY(flush_pending());                                   // restB_{b-1}: whole GPU, after the panel
         // the panel that will run next to this block column's update is panel b+1
         const int64_t rows_next = m - je;
-        const int64_t g_next = panel_wgs(h, rows_next, f.pivot);
+        const int64_t g_next = panel_wgs(h, rows_next, f.pivot, sizeof(T));
         const int reserve = std::max<int>(min_reserve, int((std::max<int64_t>(g_next, 1) + 31) / 32 * 32));
         if (reserve > std::min(max_reserve, 224)) {
             // the next panel needs (almost) the whole GPU: run this block column on one stream
@@ -805,7 +805,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     const bool fold = h->tune.gate_fold != 0 && !h->tune.gate_trace;
     const int64_t confine_rows = h->tune.confine_rows;
     auto reserve_for = [&](int64_t rows) {
-        const int64_t g = panel_wgs(h, rows, f.pivot);
+        const int64_t g = panel_wgs(h, rows, f.pivot, sizeof(T));
         return std::max<int>(32, int((g + 31) / 32 * 32));
     };
     auto wait_on = [&](hipStream_t st, size_t idx) -> int {
@@ -1998,7 +1998,7 @@ static int mgpu_getrf(Mgpu* g, int64_t n, T* const* slabs, const int64_t* lds, i
         // the update stream of every device for this block column: the next owner leaves its panel the CUs it needs
         std::vector<hipStream_t> Ub(g->U);
         if (nxt_owner >= 0 && !tall_next && D > 1) {
-            const int64_t gw = panel_wgs(g->h[nxt_owner], n - lay[b + 1].j0, pivot);
+            const int64_t gw = panel_wgs(g->h[nxt_owner], n - lay[b + 1].j0, pivot, sizeof(T));
             if (gw > 32 && big_reserve > 32) {
                 RFLU_HIP(hipSetDevice(g->devs[nxt_owner]));
                 RFLU_TRY(get_ustream(g->h[nxt_owner], (int)big_reserve, &Ub[nxt_owner]));

@@ -517,6 +517,13 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
         h->epoch += (unsigned)NB;
     }
     ProfScope ps(h, RFLU_K_PANEL, (double)rows * (double)w * (double)w);
+    if (pivot && w == NB && panel_use_blocked(h, rows, sizeof(T))) {
+        // the sub-panel kernel (panel_blocked.hip); XCD-local records for the short panels as below
+        const int64_t local_rows = h->tune.panel_local_rows >= 0 ? h->tune.panel_local_rows : (sizeof(T) == 4 ? 8192 : 4096);
+        const bool loc = h->panel_local == 1 || (h->panel_local == 2 && h->num_cus == 256 && rows <= local_rows);
+        RFLU_TRY(launch_panel_blocked<T>(h, p, loc ? 1 : 0));
+        return RFLU_OK;
+    }
     if (pivot && rows <= PANEL_THREADS && h->panel_single) {   // one workgroup, LDS only (panel_single.hip)
         RFLU_TRY(launch_panel_single<T>(h, p));
         return RFLU_OK;
@@ -584,8 +591,32 @@ template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, i
 
 int panel_resident_limit(int num_cus)
 {
-    return std::min(std::min(panel_resident_limit_f64(num_cus), panel_resident_limit_f32(num_cus)),
-                    std::min(panel_local_resident_limit_f64(num_cus), panel_local_resident_limit_f32(num_cus)));
+    return std::min(std::min(std::min(panel_resident_limit_f64(num_cus), panel_resident_limit_f32(num_cus)),
+                             std::min(panel_local_resident_limit_f64(num_cus), panel_local_resident_limit_f32(num_cus))),
+                    std::min(panel_blocked_resident_limit_f64(num_cus), panel_blocked_resident_limit_f32(num_cus)));
+}
+
+// The sub-panel kernel takes a full pivoted leaf whenever it does not need a bigger CU reservation (a multiple of 32) than the
+// 512-row workgroups of the older leaves would: Float64 workgroups hold 448 rows, so panels of 14337..16384 rows (and 28673..32768)
+// stay with the older kernel -- the block columns of N = 16384 whose update, not whose panel, sets the pace.
+bool panel_use_blocked(const Handle* h, int64_t rows, size_t esize)
+{
+    if (!h->panel_blocked || h->coop_launch) return false;
+    const int64_t rpw = esize == 8 ? PANEL_BLOCKED_ROWS_F64 : PANEL_BLOCKED_ROWS_F32;
+    const int64_t g = (rows + rpw - 1) / rpw, g_old = (rows + PANEL_THREADS - 1) / PANEL_THREADS;
+    if (g > 64) return false;
+    return (g + 31) / 32 <= (g_old + 31) / 32;
+}
+
+int64_t panel_plan_wgs(const Handle* h, int64_t rows, size_t esize, int pivot)
+{
+    rows = std::max<int64_t>(rows, 1);
+    if (pivot && panel_use_blocked(h, rows, esize)) {
+        const int64_t rpw = esize == 8 ? PANEL_BLOCKED_ROWS_F64 : PANEL_BLOCKED_ROWS_F32;
+        return (rows + rpw - 1) / rpw;
+    }
+    const int64_t rpw = (pivot && h->panel_local > 0) ? panel_local_rows_per_wg(h, rows) : PANEL_THREADS;
+    return (rows + rpw - 1) / rpw;
 }
 
 size_t panel_scratch_bytes() { return (PX_OFFSET_WORDS + PX_BYTES / 8 + RFLU_TRACE_ALL_WORDS) * sizeof(u64); }  // records | trace stamps | pair slots | all-workgroup trace

@@ -511,6 +511,13 @@ int launch_panel_local(Handle* h, const PanelArgs<T>& p, int stride, int sel, in
 template <typename T>
 int launch_panel_single(Handle* h, const PanelArgs<T>& p);
 
+// panel_blocked.hip: a full leaf as 8 sub-panels of 8 columns, one chain wave per workgroup (any number of workgroups up to 64)
+constexpr int PANEL_BLOCKED_ROWS_F64 = 7 * 64, PANEL_BLOCKED_ROWS_F32 = 8 * 64;   // rows per workgroup
+template <typename T>
+int launch_panel_blocked(Handle* h, const PanelArgs<T>& p, int local);
+int panel_blocked_resident_limit_f64(int num_cus);
+int panel_blocked_resident_limit_f32(int num_cus);
+
 int panel_resident_limit_f64(int num_cus);
 int panel_resident_limit_f32(int num_cus);
 int panel_local_resident_limit_f64(int num_cus);

@@ -173,6 +173,8 @@ struct Handle {
     // records through that XCD's L2 (needs that XCD free: experiments only)
     int panel_local = 2;
     int panel_single = 1;        // RFLU_PANEL_SINGLE: leaves of at most 512 rows in one workgroup, LDS only (panel_single.hip)
+    int panel_blocked = 0;       // RFLU_PANEL_BLOCKED=1: full pivoted leaves by the sub-panel kernel with one chain wave per workgroup (panel_blocked.hip;
+                                 // bit-identical, measured no faster than the default leaves: opt-in)
     int panel_local_maxg = 64;
     int panel_xcc = 0;
     int trsv_max_wgs = 0;        // same for the cooperative solve kernels (asked on first use)
@@ -235,6 +237,10 @@ int ensure_buffer(void** ptr, size_t* cap, size_t need);  // grow-only device bu
 
 // ---- kernel launchers (each returns an rflu_status); all pointers are device pointers in R layout -----------------------
 int panel_local_rows_per_wg(const Handle* h, int64_t rows);   // panel_local.hip: rows per workgroup of a pivoted leaf
+// panel.hip: does a full pivoted leaf of `rows` rows go to the sub-panel kernel (panel_blocked.hip), and the workgroups the leaf
+// kernel of launch_panel's choice takes (what a schedule has to keep free)
+bool panel_use_blocked(const Handle* h, int64_t rows, size_t esize);
+int64_t panel_plan_wgs(const Handle* h, int64_t rows, size_t esize, int pivot);
 int launch_heat(Handle* h, int cus, double usec);   // gemm.hip: clock keeper
 // optional early-completion signal of a GEMM launch: the tiles of the first `first_cols` columns of C are computed first and
 // the last of them publishes `val` in *flag (a stream gate, see LaswpGate); cnt: zero-initialised wrapping counter

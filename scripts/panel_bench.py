@@ -1,7 +1,8 @@
 """Per-column time of one leaf (m x 64, Float64) for the panel kernel variants, alone on the GPU, and a bit-for-bit
 comparison of their results.  Modes: 0 = the two-trip reference kernel of panel.hip (RFLU_PANEL_LOCAL=0, RFLU_PANEL_SINGLE=0),
 1 = XCD-local cooperative leaf (panel_local.hip, plain-store records on one XCD), 2 = the shipped routing (one-workgroup LDS
-leaf up to 512 rows, cooperative leaf with sc1 records on any placement above), 3 = mode 2 without the one-workgroup leaf.
+leaf up to 512 rows, cooperative leaf with sc1 records on any placement above), 3 = mode 2 without the one-workgroup leaf, 4 = the sub-panel kernel with one chain wave per workgroup (panel_blocked.hip; modes 0-3
+switch it off).
 usage: python scripts/panel_bench.py [m ...]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,8 +16,9 @@ dtype = torch.float32 if os.environ.get("PANEL_F32") else torch.float64
 sfx = "f32" if dtype == torch.float32 else "f64"
 ref = {}
 for mode in modes:
-    os.environ["RFLU_PANEL_LOCAL"] = str({0: 0, 1: 1, 2: 2, 3: 2}[mode])
+    os.environ["RFLU_PANEL_LOCAL"] = str({0: 0, 1: 1, 2: 2, 3: 2, 4: 2, 5: 1}[mode])
     os.environ["RFLU_PANEL_SINGLE"] = "0" if mode in (0, 3) else "1"
+    os.environ["RFLU_PANEL_BLOCKED"] = "1" if mode in (4, 5) else "0"
     h = _ffi.Handle(0)
     h.set_stream(None)
     for m in sizes:

@@ -228,6 +228,52 @@ def test_xcd_local_short_panels_are_bit_identical(n, dtype, monkeypatch):
         assert torch.equal(F.factors, G.factors)
 
 
+@pytest.mark.parametrize("n,dtype", [(4096, np.float64), (3000, np.float64), (9000, np.float64), (4096, np.float32), (1100, np.float32)])
+def test_subpanel_leaf_is_bit_identical(n, dtype, monkeypatch):
+    """RFLU_PANEL_BLOCKED=1 routes every full pivoted leaf to the sub-panel kernel (panel_blocked.hip: one chain wave per workgroup
+    carries the pivot search of 8 columns at a time, the other waves follow through LDS counters).  Every entry receives the
+    multiply-adds of the unblocked algorithm (src/lu.jl:290-338) with the same operands in the same order: identical factors and
+    pivots, inside the block-column schedules (offsets, XCD-local and any-placement records, one workgroup and many)."""
+    _, F = _factor(n, dtype, True, 0)
+    monkeypatch.setenv("RFLU_PANEL_BLOCKED", "1")
+    for _ in range(2):
+        _, G = _factor(n, dtype, True, 0)
+        assert F.info == G.info == 0
+        assert torch.equal(F.ipiv, G.ipiv)
+        assert torch.equal(F.factors, G.factors)
+
+
+@pytest.mark.parametrize("kind", ["ties", "zero_column", "nan", "singular"])
+def test_subpanel_leaf_special_values(kind, monkeypatch):
+    """The sub-panel kernel's general search path: exact ties (lowest position wins), an all-zero column (its first row is the
+    pivot, info reports it), NaN entries (never chosen while a number is there) -- the same pivots, info and bits as the default
+    leaves on the same input."""
+    rng = np.random.default_rng(7)
+    m = 1500
+    if kind == "ties":
+        A = rng.integers(-3, 4, size=(m, 128)).astype(np.float64)
+    else:
+        A = rng.random((m, 128))
+    if kind == "zero_column":
+        A[:, 70] = 0.0
+    if kind == "nan":
+        A[5, 3] = np.nan
+        A[900, 64] = np.nan
+    if kind == "singular":
+        A[:, 10] = A[:, 9]
+    out = []
+    for blocked in ("0", "1"):
+        monkeypatch.setenv("RFLU_PANEL_BLOCKED", blocked)
+        W = torch.from_numpy(np.ascontiguousarray(A.T)).to("cuda:0").T
+        F = rf.lu_(W, None, True, check=False)
+        out.append((F.info, F.ipiv.clone(), F.factors.clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+    a, b = out[0][2], out[1][2]
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
 @pytest.mark.parametrize("m,n,bs,dtype,pivot", [
     (3000, 2048, 128, np.float64, True),     # tall: panels of 3000 .. 952 rows
     (2048, 3000, 256, np.float64, True),     # fat: the windows of the last block column reach into the tail (src/lu.jl:148-154)

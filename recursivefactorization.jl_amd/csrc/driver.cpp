@@ -71,6 +71,8 @@ void Tune::load_env()
     env_get("RFLU_SPLIT_SHARE", split_share);
     env_get("RFLU_SPLIT_SCALE", split_scale);
     env_get("RFLU_MAX_RESERVE", max_reserve);
+    env_get("RFLU_WIDE_NARROW", wide_narrow);
+    env_get("RFLU_NARROW_COLS", narrow_cols);
     env_get("RFLU_RESERVE_CUS", min_reserve);
     env_get("RFLU_CONFINE_ROWS", confine_rows);
     env_get("RFLU_MERGE_ROWS", merge_rows);
@@ -528,8 +530,12 @@ static double model_gemm_flops_per_us(int64_t K, int cus, size_t elem)
 // b_end < number of block columns: stop after block column b_end-1 (its update issued, block column b_end brought up to date on
 // P) and hand over to factor_leafwise; *U_last = the update stream of that block column.
 template <typename T>
-static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U_last)
+static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U_last, int64_t W_wide = 0, int64_t wide_end = 0)
 {
+    // Block columns: [0, wide_end) in pieces of W_wide (a multiple of W; the update-bound part of a large matrix, whose bulk GEMM
+    // wants the deeper K), the rest in pieces of W.  A block column is numbered by its first column / W ("id"): events, gate
+    // values and b_end use that number, so the narrow part -- and factor_leafwise behind it -- see the numbering they would
+    // see without a wide part.
     Handle* h = f.h;
     // tuning knobs (Tune): split_share = how much of what is left after the modelled time stays on the update stream;
     // max_reserve: taller panels (> 64 workgroups) take too many CUs from the update: one stream instead; min_reserve: least number
@@ -541,7 +547,15 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     hipStream_t P = h->stream;
     const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
     T* R = f.R;
-    const int64_t nblk = (mn + W - 1) / W;
+    if (W_wide <= W || wide_end <= 0) { W_wide = W; wide_end = 0; }
+    wide_end = std::min(wide_end / W_wide * W_wide, mn);
+    std::vector<int64_t> bstart;
+    for (int64_t c = 0; c < mn; c += (c < wide_end ? W_wide : W)) bstart.push_back(c);
+    bstart.push_back(mn);
+    const int64_t nblk = (int64_t)bstart.size() - 1;            // block columns
+    const int64_t nid = (mn + W - 1) / W;                       // ids
+    auto id_of = [&](int64_t b) { return b >= nblk ? nid : bstart[b] / W; };
+    auto width_of = [&](int64_t b) { return b < nblk ? bstart[b + 1] - bstart[b] : W; };
     hipEvent_t ev;
     // The critical path moves between the caller's stream and a stream confined to the reserved CUs (get_pstream); h->stream
     // follows it, and is put back on every way out of this function.
@@ -554,7 +568,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     auto move_P = [&](hipStream_t to, int64_t b) -> int {
         if (to == P) return RFLU_OK;
         hipEvent_t e0;
-        RFLU_TRY(get_event(h, 4 * b + 0, &e0));
+        RFLU_TRY(get_event(h, 4 * id_of(b) + 0, &e0));
         RFLU_HIP(hipEventRecord(e0, P));
         RFLU_HIP(hipStreamWaitEvent(to, e0, 0));
         P = to;
@@ -591,13 +605,13 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         if (h->mask_failed) merge_rows = (int64_t)1 << 40;
     }
     const unsigned long long ubase = h->gate_epoch;
-    h->gate_epoch += (unsigned long long)nblk + 2;
-    auto uval = [&](int64_t b) { return ubase + (unsigned long long)b + 1; };
+    h->gate_epoch += (unsigned long long)nid + 2;
+    auto uval = [&](int64_t b) { return ubase + (unsigned long long)id_of(b) + 1; };
     bool prev_merged = false;
 
     // events: 4b+1 = evP[b], 4b+2 = evU1[b], 4b+3 = evUend[b]
     hipStream_t Uprev = nullptr;      // update stream of the previous overlapped block column
-    int64_t uend_prev = -1;           // its block index (evUend recorded), -1: none
+    int64_t uend_prev = -1;           // its id (evUend recorded), -1: none
     bool prev_overlapped = false;
     struct { bool valid = false; int64_t j0 = 0, jb = 0, c0 = 0; int64_t need_uend = -1; } pend;  // restB of block b-1
 
@@ -612,8 +626,9 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         return update(P, pend.j0, pend.jb, pend.c0, n);
     };
 
-    for (int64_t b = 0; b < std::min(nblk, b_end); ++b) {
-        const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
+    for (int64_t b = 0; b < nblk && id_of(b) < b_end; ++b) {
+        const int64_t j0 = bstart[b], jb = width_of(b), je = j0 + jb;
+        const bool last_here = !(b + 1 < nblk && id_of(b + 1) < b_end);   // the next block column is somebody else's (or there is none)
         {
             const int64_t g_b = panel_wgs(h, m - j0, f.pivot, sizeof(T));
             const int res_b = std::max<int>(min_reserve, int((std::max<int64_t>(g_b, 1) + 31) / 32 * 32));
@@ -651,7 +666,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         }
         hipStream_t U;
         RFLU_TRY(get_ustream(h, reserve, &U));
-        RFLU_TRY(get_event(h, 4 * b + 1, &ev));
+        RFLU_TRY(get_event(h, 4 * id_of(b) + 1, &ev));
         RFLU_HIP(hipEventRecord(ev, P));
         RFLU_HIP(hipStreamWaitEvent(U, ev, 0));
         if (Uprev && Uprev != U && uend_prev >= 0) {                 // a different mask: order the two update streams
@@ -667,14 +682,14 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
             RFLU_TRY(rc);
         }
         if (je >= n) {
-            RFLU_TRY(get_event(h, 4 * b + 3, &ev));
+            RFLU_TRY(get_event(h, 4 * id_of(b) + 3, &ev));
             RFLU_HIP(hipEventRecord(ev, U));
-            uend_prev = b;
+            uend_prev = id_of(b);
             Uprev = U;
             break;
         }
-        const int64_t n1e = std::min(je + W, n);                                            // end of block column b+1
-        const int64_t n2e = std::min(n1e + W, n);                                           // end of block column b+2
+        const int64_t n1e = std::min(je + width_of(b + 1), n);                              // end of block column b+1
+        const int64_t n2e = std::min(n1e + width_of(b + 2), n);                             // end of block column b+2
         // ---- P: next block column (needs rest_{b-1}.part1, which updated exactly these columns).  Handing all but its
         // first leaf to U (and gating P's second leaf on it) was measured slower: U's in-order queue is still busy with
         // rest_{b-1} in the early, update-bound block columns.
@@ -685,17 +700,17 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
                 pgate.wait_val = uval(b - 1);
                 pgate.info = h->info_dev;
             } else {
-                RFLU_TRY(get_event(h, 4 * (b - 1) + 2, &ev));
+                RFLU_TRY(get_event(h, 4 * id_of(b - 1) + 2, &ev));
                 RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
             }
         }
         RFLU_TRY(update(P, j0, jb, je, n1e, pgate));
         // ---- U: block column b+2 first (the next `next`), then as much of the rest as fits next to P's work ----
         const bool merged = m - je >= merge_rows && reserve == 32 && jb >= 256 && n2e > n1e && m > je &&
-                            !(b_end < nblk && b == b_end - 1) && b + 1 < nblk;
+                            !(b_end < nid && last_here) && b + 1 < nblk;
         if (!merged) {
             RFLU_TRY(update(U, j0, jb, n1e, n2e));
-            RFLU_TRY(get_event(h, 4 * b + 2, &ev));
+            RFLU_TRY(get_event(h, 4 * id_of(b) + 2, &ev));
             RFLU_HIP(hipEventRecord(ev, U));
         }
         int64_t cA = n;                                                                      // restA = [n2e, cA)
@@ -705,7 +720,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
             const double rateU = model_gemm_flops_per_us(jb, 256 - reserve, sizeof(T));
             const double rateP = model_gemm_flops_per_us(jb, 256, sizeof(T));
             const double col_flops = 2.0 * double(m - je) * double(jb);                      // per trailing column
-            const double tP = split_scale * ((je < mn ? model_panel_us(m - je, std::min(W, mn - je)) : 0.0)
+            const double tP = split_scale * ((je < mn ? model_panel_us(m - je, std::min(width_of(b + 1), mn - je)) : 0.0)
                                              + col_flops * double(n1e - je) / rateP);
             const double colsA = tP * rateU / col_flops;                                     // columns U finishes in tP
             const int64_t left = n - n1e;
@@ -726,7 +741,7 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
             RFLU_TRY(update(U, j0, jb, n2e, cA));
         }
         prev_merged = merged;
-        RFLU_TRY(get_event(h, 4 * b + 3, &ev));
+        RFLU_TRY(get_event(h, 4 * id_of(b) + 3, &ev));
         RFLU_HIP(hipEventRecord(ev, U));
         if (cA < n) {
             pend.valid = true;
@@ -735,18 +750,18 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
             pend.c0 = cA;
             pend.need_uend = uend_prev;   // restA_{b-1} may have written columns right of cA
         }
-        uend_prev = b;
+        uend_prev = id_of(b);
         Uprev = U;
         prev_overlapped = true;
         if (h->progress) RFLU_TRY(h->progress(j0));   // block column b-1's last piece (restB) went out after panel b: rows above j0 are settled
     }
     RFLU_TRY(flush_pending());
-    if (h->progress) RFLU_TRY(h->progress(std::min(std::min(nblk, b_end) * W, mn)));
+    if (h->progress) RFLU_TRY(h->progress(std::min(std::min(nid, b_end) * W, mn)));
     RFLU_TRY(move_P(userS, nblk));
     f.sw_lo = 0;
     f.sw_hi = -1;
     if (U_last) *U_last = Uprev;
-    if (b_end < nblk) return RFLU_OK;   // factor_leafwise goes on from here and joins at its end
+    if (b_end < nid) return RFLU_OK;   // factor_leafwise goes on from here and joins at its end
     // join: P continues only after U has drained
     if (uend_prev >= 0) {
         RFLU_TRY(get_event(h, 4 * uend_prev + 3, &ev));
@@ -991,6 +1006,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
 
     Fact<T> f{h, R, ld, m, n, ipiv, pivot};
     bool fat_tail_done = false;
+    const bool default_bs = blocksize == 0;
     if (blocksize == 0) blocksize = default_blocksize(mn);
     // column-major entry with the tail of the layout change still in flight (getrf_cm_dev): only factor_lookahead knows where the
     // first access to those columns is; every other path waits for it here
@@ -1021,7 +1037,18 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             if (h->mask_failed) leafwise = 0;
             if (!h->mask_failed) RFLU_TRY(validate_queues(h));
         }
-        const int64_t Wb = round_up(blocksize, NB);
+        int64_t Wb = round_up(blocksize, NB);
+        // Large matrices with the default block width: WIDE block columns (1024 / 2048: the bulk GEMM at K >= 1024 runs at 0.88-0.91 of
+        // the MFMA peak instead of 0.83) while the update is the bottleneck, i.e. up to the last `narrow_cols` columns; those are
+        // factored the way a matrix of that size is -- 512-wide block columns, leaf-wise from 8192 rows on -- because there the
+        // chain of panels sets the pace and a 2048-column recursion on the critical path is what costs.
+        int64_t W_wide = 0, wide_end = 0;
+        if (default_bs && h->tune.wide_narrow && Wb > 512 && mn >= 20480) {
+            const int64_t narrow_cols = std::max<int64_t>(h->tune.narrow_cols, 2048);
+            W_wide = Wb;
+            Wb = 512;
+            wide_end = std::max<int64_t>(mn - narrow_cols, 0) / W_wide * W_wide;
+        }
         const auto t_enq0 = std::chrono::steady_clock::now();
         const int64_t nblk = (mn + Wb - 1) / Wb;
         int64_t b_switch = nblk;   // first block column of the leaf-wise part
@@ -1035,6 +1062,8 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             lw_rows = std::min<int64_t>(lw_rows, 32 * (int64_t)PANEL_THREADS);
             b_switch = m <= lw_rows ? 0 : std::min(nblk, (m - lw_rows + Wb - 1) / Wb);
         }
+        // the block column in front of the leaf-wise part has to be a narrow one (factor_leafwise finds its events by number)
+        if (W_wide > 0 && b_switch < nblk) wide_end = std::min(wide_end, std::max<int64_t>(b_switch - 1, 0) * Wb / W_wide * W_wide);
         hipStream_t U_last = nullptr;
         {
             if (tail && b_switch == 0) {
@@ -1042,7 +1071,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
                 tail = nullptr;
             }
             f.tail = tail;
-            if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last));
+            if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last, W_wide, wide_end));
             if (b_switch < nblk) RFLU_TRY(factor_leafwise<T>(f, Wb, b_switch, U_last));
         }
         if (h->tune.time_enqueue)

@@ -76,6 +76,8 @@ struct Tune {
     double split_share = 0.5;          // RFLU_SPLIT_SHARE
     double split_scale = 1.0;          // RFLU_SPLIT_SCALE
     int max_reserve = 64;              // RFLU_MAX_RESERVE
+    int wide_narrow = 1;               // RFLU_WIDE_NARROW: default block width of matrices of 20480 columns and more = wide, then 512 for the last ...
+    int64_t narrow_cols = 16384;       // RFLU_NARROW_COLS: ... this many columns
     int min_reserve = 32;              // RFLU_RESERVE_CUS
     int64_t confine_rows = (int64_t)1 << 40;   // RFLU_CONFINE_ROWS
     int64_t merge_rows = -1;           // RFLU_MERGE_ROWS (-1: 8192 Float64, never Float32)

@@ -83,26 +83,25 @@ __device__ __forceinline__ void block_load(const T* __restrict__ M, int64_t ldm,
 
 // y[i][c] = sum_k M[i][k] * xs[k][c] with M in registers (block_load); the four column quarters meet in LDS `part`.
 // y is valid in the threads with q == 0.
-template <typename T>
-__device__ __forceinline__ void block_gemv(const T (&m)[16], const T* xs, T* part, int tid, T (&y)[TV_NR])
+template <typename T, int NR>
+__device__ __forceinline__ void block_gemv(const T (&m)[16], const T* xs, T* part, int tid, T (&y)[NR])
 {
     const int i = tid & 63, q = tid >> 6;
-    T acc[TV_NR];
+    T acc[NR];
 #pragma unroll
-    for (int c = 0; c < TV_NR; ++c) acc[c] = T(0);
+    for (int c = 0; c < NR; ++c) acc[c] = T(0);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
 #pragma unroll
-        for (int c = 0; c < TV_NR; ++c) acc[c] += m[k] * xs[(q * 16 + k) * TV_NR + c];
+        for (int c = 0; c < NR; ++c) acc[c] += m[k] * xs[(q * 16 + k) * NR + c];
     }
 #pragma unroll
-    for (int c = 0; c < TV_NR; ++c) part[(q * NB + i) * TV_NR + c] = acc[c];
+    for (int c = 0; c < NR; ++c) part[(q * NB + i) * NR + c] = acc[c];
     __syncthreads();
     if (q == 0) {
 #pragma unroll
-        for (int c = 0; c < TV_NR; ++c)
-            y[c] = (part[i * TV_NR + c] + part[(NB + i) * TV_NR + c]) +
-                   (part[(2 * NB + i) * TV_NR + c] + part[(3 * NB + i) * TV_NR + c]);
+        for (int c = 0; c < NR; ++c)
+            y[c] = (part[i * NR + c] + part[(NB + i) * NR + c]) + (part[(2 * NB + i) * NR + c] + part[(3 * NB + i) * NR + c]);
     }
     __syncthreads();  // `part` may be reused
 }
@@ -138,33 +137,77 @@ __device__ __forceinline__ bool tv_load(__amdgpu_buffer_rsrc_t r, unsigned off, 
     return x[1] == tag && x[3] == tag;
 }
 
+// M_r = inv(D_rr) * T_{r,p}  for the block p solved right before r (p = r-1 in the lower, r+1 in the upper triangle): with it
+// the solve of block r needs ONE 64x64 product once x_p is known (x_r = y_r - M_r x_p, y_r = inv(D_rr) (b_r - everything
+// before p), which its owner has had a whole stage to prepare) instead of two dependent ones.  One workgroup per block.
 template <typename T, bool UPPER>
-__global__ void __launch_bounds__(TV_THREADS) trsv_coop_kernel(int n, int nrhs, const T* __restrict__ R, int64_t ld,
-                                                               const T* __restrict__ Dinv, T* X, int64_t ldx,
-                                                               void* xchg, unsigned xchg_bytes, unsigned tag, int64_t* err)
+__global__ void __launch_bounds__(256) trsv_sub_kernel(int n, const T* __restrict__ R, int64_t ld, const T* __restrict__ Dinv,
+                                                       T* __restrict__ Msub)
+{
+    __shared__ T sT[NB * (NB + 1)];
+    __shared__ T sD[NB * (NB + 1)];
+    const int nb = (n + NB - 1) / NB;
+    const int r = blockIdx.x, p = UPPER ? r + 1 : r - 1;
+    const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    T* out = Msub + (size_t)r * NB * NB;
+    if (p < 0 || p >= nb) {
+        for (int k = 0; k < 16; ++k) out[i * NB + q * 16 + k] = T(0);
+        return;
+    }
+    const int rows_ok = min(NB, n - r * NB), cols_ok = min(NB, n - p * NB);
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int a = e >> 6, c = e & 63;
+        sT[a * (NB + 1) + c] = (a < rows_ok && c < cols_ok) ? R[(int64_t)(r * NB + a) * ld + p * NB + c] : T(0);
+        sD[a * (NB + 1) + c] = Dinv[(size_t)r * NB * NB + e];
+    }
+    __syncthreads();
+    T acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = T(0);
+    for (int k = 0; k < NB; ++k) {
+        const T dk = sD[i * (NB + 1) + k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] += dk * sT[k * (NB + 1) + q * 16 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[i * NB + q * 16 + k] = acc[k];
+}
+
+// One triangle, NR right-hand sides.  Block r of the right-hand sides belongs to workgroup r mod G; blocks are solved in
+// order (0, 1, ... in the lower, nb-1, nb-2, ... in the upper triangle), stage d = "x_d is known".  The chain per stage is
+//   owner of the NEXT block:  wait for x_d (one hop)  ->  x_next = y_next - M_next x_d (one 64x64 product)  ->  publish;
+// everything else trails: every workgroup subtracts T_rd x_d from the blocks r it owns further on (each 64x64 block of the
+// triangle is read exactly once, the nearest one from registers filled a stage ago), and the owner of the block after next
+// prepares y = inv(D) b for it as soon as x_d has been applied to it.  Workgroups whose turn is more than two stages away
+// poll at leisure (with 256 of them polling flat out the hop of the one that matters takes twice as long).
+template <typename T, bool UPPER, int NR>
+__global__ void __launch_bounds__(TV_THREADS) trsv_chain_kernel(int n, int nrhs, const T* __restrict__ R, int64_t ld,
+                                                                const T* __restrict__ Dinv, const T* __restrict__ Msub, T* X, int64_t ldx,
+                                                                void* xchg, unsigned xchg_bytes, unsigned tag, int64_t* err)
 {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xchg, 0, xchg_bytes, 0x00020000);
-    __shared__ T xs[NB * TV_NR];
-    __shared__ T part[4 * NB * TV_NR];
-    __shared__ T bacc[TV_KOWN][NB * TV_NR];   // the owned blocks of B: they stay here until they become x
+    __shared__ T xs[NB * NR];                 // x_d of the current stage
+    __shared__ T xnext[NB * NR];              // x of the block this workgroup has just solved (next stage's x_d)
+    __shared__ T yv[NB * NR];                 // y of the block this workgroup solves next
+    __shared__ T part[4 * NB * NR];
+    __shared__ T bacc[TV_KOWN][NB * NR];      // the owned blocks of B: they stay here until they become x
     __shared__ int s_dead;
     const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
     const int nb = (n + NB - 1) / NB;
     const int G = gridDim.x, w = blockIdx.x;
+    const int dir = UPPER ? -1 : 1;
     if (tid == 0) s_dead = 0;
-    // owned block j is block w + j*G; load them all
     for (int j = 0; j < TV_KOWN; ++j) {
         const int r = w + j * G;
-        for (int e = tid; e < NB * TV_NR; e += TV_THREADS) {
-            const int k = e / TV_NR, c = e % TV_NR;
+        for (int e = tid; e < NB * NR; e += TV_THREADS) {
+            const int k = e / NR, c = e % NR;
             bacc[j][e] = (r < nb && r * NB + k < n && c < nrhs) ? X[(int64_t)(r * NB + k) * ldx + c] : T(0);
         }
     }
-    // the diagonal inverse of the block this workgroup solves next, and the off-diagonal block of its nearest owned block
-    // for the first stage: both requested before the first flag is waited for
     const int d0 = UPPER ? nb - 1 : 0;
-    auto nearest = [&](int d) -> int {   // nearest owned block strictly beyond stage d (or -1)
+    auto owned_beyond = [&](int d) -> int {   // nearest owned block strictly beyond block d in solve order (or -1)
         if (!UPPER) {
+            if (d + 1 >= nb) return -1;
             const int r = d + 1 + ((w - (d + 1)) % G + G) % G;
             return r < nb ? r : -1;
         }
@@ -172,51 +215,69 @@ __global__ void __launch_bounds__(TV_THREADS) trsv_coop_kernel(int n, int nrhs, 
         const int r = d - 1 - (((d - 1) - w) % G + G) % G;
         return r >= 0 ? r : -1;
     };
-    auto first_own = [&]() -> int {      // the first block this workgroup will have to solve
-        if (!UPPER) return w < nb ? w : -1;
-        const int r = (nb - 1) - (((nb - 1) - w) % G + G) % G;
-        return r >= 0 ? r : -1;
+    auto slot = [&](int r) -> int { return (r - w) / G; };
+    auto load_T = [&](int r, int d, T (&m)[16]) {
+        block_load<T>(R + (int64_t)r * NB * ld + d * NB, ld, min(NB, n - r * NB), min(NB, n - d * NB), tid, m);
     };
-    int next_solve = first_own();
-    T dinv[16], mnear[16];
-    if (next_solve >= 0) block_load<T>(Dinv + (size_t)next_solve * NB * NB, NB, NB, NB, tid, dinv);
-    {
-        const int rn = nearest(d0);
-        if (rn >= 0)
-            block_load<T>(R + (int64_t)rn * NB * ld + d0 * NB, ld, min(NB, n - rn * NB), min(NB, n - d0 * NB), tid, mnear);
+    // publish the block just solved (y in the q == 0 threads) as x_r: granules for the other workgroups, xnext for this one, X
+    auto publish = [&](int r, const T (&y)[NR]) {
+        if (q == 0) {
+            const int rn = min(NB, n - r * NB);
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                tv_store(rx, (unsigned)((r * NB + i) * NR + c) * 16u, tag, y[c]);
+                xnext[i * NR + c] = y[c];
+                if (i < rn && c < nrhs) X[(int64_t)(r * NB + i) * ldx + c] = y[c];
+            }
+        }
+    };
+    int ns = UPPER ? ((nb - 1) - (((nb - 1) - w) % G + G) % G) : w;   // the block this workgroup solves next (-1: none left)
+    if (ns < 0 || ns >= nb) ns = -1;
+    T dinv[16], mcrit[16], mnear[16];
+    if (ns >= 0) {
+        block_load<T>(Dinv + (size_t)ns * NB * NB, NB, NB, NB, tid, dinv);
+        block_load<T>(Msub + (size_t)ns * NB * NB, NB, NB, NB, tid, mcrit);
+    }
+    __syncthreads();
+    // blocks without two predecessors: the first one is solved outright, the second one has its y before the first stage
+    if (ns == d0 || ns == d0 + dir) {
+        T y[NR];
+        block_gemv<T, NR>(dinv, bacc[slot(ns)], part, tid, y);
+        if (ns == d0) {
+            publish(ns, y);
+            ns = ns + dir * G;
+            if (ns < 0 || ns >= nb) ns = -1;
+            if (ns >= 0) {
+                block_load<T>(Dinv + (size_t)ns * NB * NB, NB, NB, NB, tid, dinv);
+                block_load<T>(Msub + (size_t)ns * NB * NB, NB, NB, NB, tid, mcrit);
+            }
+        } else if (q == 0) {
+#pragma unroll
+            for (int c = 0; c < NR; ++c) yv[i * NR + c] = y[c];
+        }
+    }
+    {   // the off-diagonal block of the first stage's nearest trailing block (not the block solved next: that one uses mcrit)
+        int rn = owned_beyond(d0);
+        if (rn == d0 + dir) rn = owned_beyond(rn);
+        if (rn >= 0) load_T(rn, d0, mnear);
     }
     __syncthreads();
 
-    for (int s = 0; s < nb; ++s) {
-        const int d = UPPER ? nb - 1 - s : s;
-        const int dn = min(NB, n - d * NB);   // rows (= columns) of diagonal block d
-        const int owner = d % G;
-        if (w == owner) {
-            // b_d is complete (every earlier stage has been applied to it): x_d = inv(D_dd) * b_d
-            const int jd = (d - w) / G;
-            for (int e = tid; e < NB * TV_NR; e += TV_THREADS) xs[e] = bacc[jd][e];
-            __syncthreads();
-            T y[TV_NR];
-            block_gemv<T>(dinv, xs, part, tid, y);
-            if (q == 0) {
-#pragma unroll
-                for (int c = 0; c < TV_NR; ++c) {
-                    tv_store(rx, (unsigned)((d * NB + i) * TV_NR + c) * 16u, tag, y[c]);   // to the other workgroups
-                    xs[i * TV_NR + c] = y[c];
-                    if (i < dn && c < nrhs) X[(int64_t)(d * NB + i) * ldx + c] = y[c];        // the result
-                }
-            }
-            __syncthreads();
-            next_solve = UPPER ? d - G : d + G;
-            if (next_solve >= 0 && next_solve < nb) block_load<T>(Dinv + (size_t)next_solve * NB * NB, NB, NB, NB, tid, dinv);
+    for (int s = 0; s + 1 < nb; ++s) {   // the last block's x has nobody to go to
+        const int d = d0 + dir * s, dnext = d + dir;
+        // ---- x_d
+        if (w == d % G) {
+            for (int e = tid; e < NB * NR; e += TV_THREADS) xs[e] = xnext[e];
         } else {
+            const bool urgent = ns >= 0 && (ns == dnext || ns == dnext + dir);
             bool timed_out = false;
-            for (int e = tid; e < NB * TV_NR; e += TV_THREADS) {
+            for (int e = tid; e < NB * NR; e += TV_THREADS) {
                 T v = T(0);
                 int spins = 0;
                 for (;;) {
                     asm volatile("" ::: "memory");   // plain buffer intrinsics: keep the load inside the loop
-                    if (tv_load(rx, (unsigned)(d * NB * TV_NR + e) * 16u, tag, v)) break;
+                    if (tv_load(rx, (unsigned)(d * NB * NR + e) * 16u, tag, v)) break;
+                    if (!urgent) __builtin_amdgcn_s_sleep(8);
                     if (++spins > TV_SPIN_LIMIT) { timed_out = true; break; }
                 }
                 xs[e] = v;
@@ -225,42 +286,77 @@ __global__ void __launch_bounds__(TV_THREADS) trsv_coop_kernel(int n, int nrhs, 
                 s_dead = 1;
                 __hip_atomic_store((unsigned long long*)(err + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __syncthreads();
-            if (s_dead) return;
         }
-        // subtract T_rd * x_d from the owned blocks beyond d.  The nearest one first, from the block requested a stage ago;
-        // then request the nearest block of the NEXT stage, so that its memory latency hides behind the next flag wait.
-        const int rn = nearest(d);
-        if (rn >= 0) {
-            T y[TV_NR];
-            block_gemv<T>(mnear, xs, part, tid, y);
+        __syncthreads();
+        if (s_dead) return;
+        // ---- the chain: the next block is this workgroup's
+        if (ns == dnext) {
+            T y[NR];
+            block_gemv<T, NR>(mcrit, xs, part, tid, y);
             if (q == 0) {
-                const int jr = (rn - w) / G;
 #pragma unroll
-                for (int c = 0; c < TV_NR; ++c) bacc[jr][i * TV_NR + c] -= y[c];
+                for (int c = 0; c < NR; ++c) y[c] = yv[i * NR + c] - y[c];
+            }
+            publish(ns, y);
+            ns = ns + dir * G;
+            if (ns < 0 || ns >= nb) ns = -1;
+            if (ns >= 0) {
+                block_load<T>(Dinv + (size_t)ns * NB * NB, NB, NB, NB, tid, dinv);
+                block_load<T>(Msub + (size_t)ns * NB * NB, NB, NB, NB, tid, mcrit);
             }
         }
-        const int dnext = UPPER ? d - 1 : d + 1;
-        if (dnext >= 0 && dnext < nb) {
-            const int rnn = nearest(dnext);
-            if (rnn >= 0)
-                block_load<T>(R + (int64_t)rnn * NB * ld + dnext * NB, ld, min(NB, n - rnn * NB), min(NB, n - dnext * NB), tid,
-                              mnear);
+        // ---- T_rd x_d off the blocks owned further on: the nearest first (registers), then the request for the next stage's
+        int rn = owned_beyond(d);
+        if (rn == dnext) rn = owned_beyond(rn);
+        if (rn >= 0) {
+            T y[NR];
+            block_gemv<T, NR>(mnear, xs, part, tid, y);
+            if (q == 0) {
+#pragma unroll
+                for (int c = 0; c < NR; ++c) bacc[slot(rn)][i * NR + c] -= y[c];
+            }
+        }
+        if (s + 2 < nb) {
+            int rnn = owned_beyond(dnext);
+            if (rnn == dnext + dir) rnn = owned_beyond(rnn);
+            if (rnn >= 0) load_T(rnn, dnext, mnear);
+        }
+        // ---- the block after next is this workgroup's: everything but x_next has reached it, its y can be prepared
+        if (rn >= 0 && rn == dnext + dir && rn == ns) {
+            __syncthreads();
+            T y[NR];
+            block_gemv<T, NR>(dinv, bacc[slot(ns)], part, tid, y);
+            if (q == 0) {
+#pragma unroll
+                for (int c = 0; c < NR; ++c) yv[i * NR + c] = y[c];
+            }
         }
         if (rn >= 0) {
-            for (int r = UPPER ? rn - G : rn + G; r >= 0 && r < nb; r += UPPER ? -G : G) {
-                T m[16], y[TV_NR];
-                block_load<T>(R + (int64_t)r * NB * ld + d * NB, ld, min(NB, n - r * NB), dn, tid, m);
-                block_gemv<T>(m, xs, part, tid, y);
+            for (int r = rn + dir * G; r >= 0 && r < nb; r += dir * G) {
+                T m[16], y[NR];
+                load_T(r, d, m);
+                block_gemv<T, NR>(m, xs, part, tid, y);
                 if (q == 0) {
-                    const int jr = (r - w) / G;
 #pragma unroll
-                    for (int c = 0; c < TV_NR; ++c) bacc[jr][i * TV_NR + c] -= y[c];
+                    for (int c = 0; c < NR; ++c) bacc[slot(r)][i * NR + c] -= y[c];
                 }
             }
         }
-        __syncthreads();  // this stage's updates are in bacc before the next stage reads it
+        __syncthreads();  // this stage's updates are in bacc / yv / xnext before the next stage reads them
     }
+}
+
+template <typename T, int NR>
+static int launch_trsv_pass(Handle* h, unsigned grid, int64_t n, int nr, const T* R, int64_t ld, const T* Linv, const T* Uinv, const T* Lsub,
+                            const T* Usub, T* B, int64_t ldb, void* xchg, size_t xchg_bytes)
+{
+    ProfScope ps(h, RFLU_K_TRSM, 2.0 * (double)n * (double)n * (double)nr, sizeof(T) * (double)n * (double)n);
+    hipLaunchKernelGGL((trsv_chain_kernel<T, false, NR>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Linv, Lsub, B, ldb,
+                       xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev);
+    hipLaunchKernelGGL((trsv_chain_kernel<T, true, NR>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Uinv, Usub, B, ldb,
+                       xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
 }
 
 // B <- U^-1 L^-1 B for nrhs <= TV_NR per pass (row-major factors R, row-major B); interchanges already applied to B.
@@ -269,15 +365,19 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
 {
     if (n <= 0 || nrhs <= 0) return RFLU_OK;
     const int64_t nb = (n + NB - 1) / NB;
-    // workspace: inverted diagonal blocks of L and of U, then the exchange area (one 16-byte granule per value of x)
+    // workspace: inverted diagonal blocks of L and of U, their products with the blocks next to the diagonal, then the exchange
+    // area (one 16-byte granule per value of x)
     const size_t inv_bytes = (size_t)nb * NB * NB * sizeof(T);
     const size_t xchg_bytes = (size_t)nb * NB * TV_NR * 16;
-    const size_t need = 2 * inv_bytes + xchg_bytes;
+    const size_t need = 4 * inv_bytes + xchg_bytes;
     const bool fresh = need > h->linv_tmp_bytes;
     RFLU_TRY(ensure_buffer(&h->linv_tmp, &h->linv_tmp_bytes, need));
-    T* Linv = static_cast<T*>(h->linv_tmp);
-    T* Uinv = reinterpret_cast<T*>(static_cast<char*>(h->linv_tmp) + inv_bytes);
-    void* xchg = static_cast<char*>(h->linv_tmp) + 2 * inv_bytes;
+    char* base = static_cast<char*>(h->linv_tmp);
+    T* Linv = reinterpret_cast<T*>(base);
+    T* Uinv = reinterpret_cast<T*>(base + inv_bytes);
+    T* Lsub = reinterpret_cast<T*>(base + 2 * inv_bytes);
+    T* Usub = reinterpret_cast<T*>(base + 3 * inv_bytes);
+    void* xchg = base + 4 * inv_bytes;
     // tags: a fresh (or re-purposed) area is wiped once; afterwards every launch uses its own tag from the handle's counter
     if (fresh || h->trsv_tag > 0xfffffff0u || h->trsv_area != xchg) {
         RFLU_HIP(hipMemsetAsync(h->linv_tmp, 0, need, h->stream));
@@ -286,8 +386,10 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
     }
     RFLU_TRY(launch_diag_inv<T>(h, n, R, ld, Linv));
     {
-        ProfScope ps(h, RFLU_K_TRSM, (double)n * NB * NB / 3.0);
+        ProfScope ps(h, RFLU_K_TRSM, (double)n * NB * NB / 3.0 + 4.0 * (double)n * NB * NB);
         hipLaunchKernelGGL(triu_inv_kernel<T>, dim3((unsigned)nb), dim3(64), 0, h->stream, (int)n, R, ld, Uinv);
+        hipLaunchKernelGGL((trsv_sub_kernel<T, false>), dim3((unsigned)nb), dim3(256), 0, h->stream, (int)n, R, ld, Linv, Lsub);
+        hipLaunchKernelGGL((trsv_sub_kernel<T, true>), dim3((unsigned)nb), dim3(256), 0, h->stream, (int)n, R, ld, Uinv, Usub);
         RFLU_HIP(hipGetLastError());
     }
     if (nb > (int64_t)TV_MAX_WGS * TV_KOWN) {
@@ -298,8 +400,8 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
     {   // the stages wait for each other's results: every workgroup of a launch must be resident (asked once per handle)
         if (h->trsv_max_wgs == 0) {
             int a = 0, b = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&trsv_coop_kernel<T, false>), TV_THREADS, 0) != hipSuccess ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&trsv_coop_kernel<T, true>), TV_THREADS, 0) != hipSuccess) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&trsv_chain_kernel<T, false, TV_NR>), TV_THREADS, 0) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&trsv_chain_kernel<T, true, TV_NR>), TV_THREADS, 0) != hipSuccess) {
                 (void)hipGetLastError();
                 a = b = 0;
             }
@@ -312,12 +414,8 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
     }
     for (int64_t c0 = 0; c0 < nrhs; c0 += TV_NR) {
         const int nr = (int)std::min<int64_t>(TV_NR, nrhs - c0);
-        ProfScope ps(h, RFLU_K_TRSM, 2.0 * (double)n * (double)n * (double)nr, sizeof(T) * (double)n * (double)n);
-        hipLaunchKernelGGL((trsv_coop_kernel<T, false>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Linv,
-                           B + c0, ldb, xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev);
-        hipLaunchKernelGGL((trsv_coop_kernel<T, true>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Uinv,
-                           B + c0, ldb, xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev);
-        RFLU_HIP(hipGetLastError());
+        if (nr == 1) RFLU_TRY((launch_trsv_pass<T, 1>(h, grid, n, nr, R, ld, Linv, Uinv, Lsub, Usub, B + c0, ldb, xchg, xchg_bytes)));
+        else RFLU_TRY((launch_trsv_pass<T, TV_NR>(h, grid, n, nr, R, ld, Linv, Uinv, Lsub, Usub, B + c0, ldb, xchg, xchg_bytes)));
     }
     return RFLU_OK;
 }

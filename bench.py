@@ -511,7 +511,41 @@ def main():
         r = A0.T.to(torch.float64) @ rhs.to(torch.float64) - bvec.to(torch.float64)
         berr = float((torch.linalg.norm(r) / (torch.linalg.norm(A0.to(torch.float64)) * torch.linalg.norm(rhs.to(torch.float64)))).item())
         del A0
+        # the solve step ldiv!(F, b) for ONE right-hand side on pivoted factors (what LinearSolve calls right after lu!): both
+        # triangles + the interchanges of b, HIP events on the launch stream
+        ipd = ipiv if pivot else None
+        bsol = torch.rand(n, dtype=tdt, device=dev)
+        bkeep = bsol.clone()
+        def time_solve(entry):
+            def solve_once():
+                h.call(entry, n, 1, ctypes.c_void_p(A.data_ptr()), n, ctypes.c_void_p(ipd.data_ptr() if ipd is not None else 0),
+                       ctypes.c_void_p(bsol.data_ptr()), n if "rm" not in entry else 16)
+            solve_once(); barrier()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(5):
+                bsol.copy_(bkeep)
+                solve_once()
+            s1.record()
+            barrier()
+            return s0.elapsed_time(s1) / 5
+        regenerate(); step(); barrier()
+        solve_cm_ms = time_solve(f"rflu_getrs_{sfx}_dev")          # column-major factors: + one transpose of F into the row-major workspace
+        solve_ms = None
+        if n % 16 == 0:
+            regenerate(); barrier()
+            h.call(f"rflu_getrf_rm_{sfx}_dev", n, n, ctypes.c_void_p(A.data_ptr()), n, ctypes.c_void_p(ipiv.data_ptr()), 1, 0, ctypes.byref(info))
+            bsol16 = torch.zeros((n, 16), dtype=tdt, device=dev)   # row-major n x 1 right-hand side with leading dimension 16
+            bsol16[:, 0] = bkeep
+            bkeep, bsol = bsol16.clone(), bsol16
+            solve_ms = time_solve(f"rflu_getrs_rm_{sfx}_dev")      # the factors as the library keeps them: the solve kernels alone
         variants = {
+            "solve_ms": round(solve_ms, 3) if solve_ms is not None else None,
+            "solve_cm_ms": round(solve_cm_ms, 3),
+            "solve_note": "ldiv!(F, b), one right-hand side, pivoted factors: interchanges of b + L and U solves (csrc/trsv.hip: one "
+                          "cooperative launch per triangle).  solve_ms: rflu_getrs_rm_*_dev on row-major factors (the solve kernels alone; "
+                          "algorithmic bytes sizeof(T) * n^2); solve_cm_ms: rflu_getrs_*_dev on column-major factors (+ one transpose of F)",
+            "solve_gbs": round(esz * n * n / (solve_ms * 1e-3) / 1e9, 1) if solve_ms else None,
             "nopivot": {"ms": round(1e3 * t_np, 3), "gflops": round(flops / t_np / 1e9, 1),
                         "frac_of_mfma_peak": round(flops / t_np / 1e12 / PEAK_TFLOPS[sfx], 4),
                         "note": "lu!(A, Val(false)) on the same uniform input (step = refill + lu!); residual not meaningful without pivoting"},

@@ -50,6 +50,9 @@ void Tune::load_env()
     *this = Tune();
     env_get("RFLU_PANEL_PW", panel_pw);
     env_get("RFLU_PANEL_MAXG", panel_maxg);
+    env_get("RFLU_PANEL_RPW", panel_rpw);
+    env_get("RFLU_PANEL_SPARE", panel_spare);
+    env_get("RFLU_PANEL_SPARE_MIN", panel_spare_min);
     env_get("RFLU_PANEL_BALLAST", panel_ballast);
     env_get("RFLU_PANEL_LOCAL_MIN", panel_local_min);
     env_get("RFLU_PANEL_LOCAL_ROWS", panel_local_rows);

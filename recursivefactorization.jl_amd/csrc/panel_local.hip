@@ -121,8 +121,8 @@ __device__ __forceinline__ void x_w0_publish(XLds<T>* sh, u64* scratch, unsigned
     epoch = uni(epoch);
     c1 = uni(c1);
     g = uni(g);
-    const int r = lane & (PW - 1);
     const bool has = lane < PW;   // lanes 0..PW-1 hold the wave records
+    const int r = has ? lane : 0;
     const XRec<T>* rc = &sh->rec[r];
     unsigned hi = rc->hi, lo = rc->lo, cp = rc->pos;
     const T a1 = rc->a1, a2 = rc->a2, l = rc->l;
@@ -362,8 +362,13 @@ struct XSteps {
 // dependent instruction chain between the barriers runs without a second wave sharing the issue slots) while the panel's
 // rows still fit 32 such workgroups.  Full leaves only (w == NB; launch_panel sends a narrower last leaf to the kernels of
 // panel.hip / panel_single.hip): the 64 steps are straight-line code without run-time column tests.
-template <typename T, bool LOCAL, int PW>
-__global__ void __launch_bounds__(PW * 64 + 64) panel_pivot_local_kernel(LocalArgs<T> la)
+// SP (PW = 6): the communication wave gets a SIMD for itself.  The waves of a workgroup go round the four SIMDs in a fixed cycle
+// (waves w, w + 4, w + 8 share one: scripts/probes/simdmap.hip), so in the 9-wave workgroup of PW = 8 the communication wave sits on
+// a SIMD with two row waves whose multiply-adds fill it, and every one of its ~400 instructions per column waits for them (publish
+// 900 clocks, poll-to-hand-over 3600+, against 450 / 2400 for a wave by itself).  Here the workgroup is launched with 9 waves of
+// which waves 0 and 4 leave at once: wave 8 has their SIMD, the six row waves (384 rows) the other three.
+template <typename T, bool LOCAL, int PW, int SP = 0>
+__global__ void __launch_bounds__((SP ? PW + 3 : PW + 1) * 64) panel_pivot_local_kernel(LocalArgs<T> la)
 {
     constexpr int AUX = LOCAL ? 0 : AUX_SC1;
     // LOCAL: the participants are the blocks that RUN on the chosen XCD.  A launch spreads its blocks round-robin over the
@@ -374,7 +379,14 @@ __global__ void __launch_bounds__(PW * 64 + 64) panel_pivot_local_kernel(LocalAr
     const PanelArgs<T>& p = la.p;
     __shared__ XLds<T> s_lds;
     XLds<T>* const sh = &s_lds;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
+    int wave = (int)(threadIdx.x >> 6);
+    if constexpr (SP != 0) {
+        static_assert(SP == 0 || PW == 6, "the spare-SIMD variant is laid out for 6 row waves in a 9-wave launch");
+        if (wave == 0 || wave == 4) return;
+        wave = wave == 8 ? PW : wave - 1 - (wave > 4 ? 1 : 0);
+    }
+    const int tid = wave * 64 + lane;
     const int g = (int)(blockIdx.x / (unsigned)la.stride);
     const int row = p.r0 + g * (PW * 64) + tid;
     // waves 0..7 own one matrix row per thread; wave 8 is the communication wave (no rows): it alone runs the exchange, at
@@ -467,6 +479,8 @@ int launch_panel_local_variant<pl_t, PL_LOCAL>(Handle* h, const LocalArgs<pl_t>&
         else hipLaunchKernelGGL((panel_pivot_local_kernel<T, LOCAL, 2>), grid, dim3(2 * 64 + 64), (size_t)ballast, h->stream, la);
     } else if (rpw == 256) {
         hipLaunchKernelGGL((panel_pivot_local_kernel<T, LOCAL, 4>), grid, dim3(4 * 64 + 64), 0, h->stream, la);
+    } else if (rpw == 384) {
+        hipLaunchKernelGGL((panel_pivot_local_kernel<T, LOCAL, 6, 1>), grid, dim3(9 * 64), 0, h->stream, la);
     } else {
         hipLaunchKernelGGL((panel_pivot_local_kernel<T, LOCAL, 8>), grid, dim3(8 * 64 + 64), 0, h->stream, la);
     }
@@ -505,7 +519,9 @@ int panel_local_rows_per_wg(const Handle* h, int64_t rows)
     const int max_g = h->tune.panel_maxg;
     if (floor_pw <= 1 && (rows + 63) / 64 <= max_g) return 64;
     if (floor_pw <= 2 && (rows + 127) / 128 <= max_g) return 128;
-    if (floor_pw <= 4 && (rows + 255) / 256 <= 32) return 256;
+    if (h->tune.panel_rpw > 0) return h->tune.panel_rpw;   // RFLU_PANEL_RPW: experiments
+    if (floor_pw <= 4 && (rows + 255) / 256 <= 32 && !(h->tune.panel_spare && rows > h->tune.panel_spare_min)) return 256;
+    if (h->tune.panel_spare && floor_pw <= 6 && (rows + 383) / 384 <= 32) return 384;   // 6 row waves, the communication wave on a SIMD of its own
     return 512;
 }
 #else

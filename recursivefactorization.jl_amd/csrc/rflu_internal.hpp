@@ -52,6 +52,9 @@ struct ProfSlot {
 struct Tune {
     // leaf panel
     int panel_pw = 0;                  // RFLU_PANEL_PW: floor for the row waves per cooperative workgroup (1|2|4|8)
+    int panel_rpw = 0;                 // RFLU_PANEL_RPW: rows per workgroup of the cooperative leaf, forced (64|128|256|384|512; experiments)
+    int panel_spare = 1;               // RFLU_PANEL_SPARE: 384-row workgroups whose communication wave has a SIMD for itself, for panels of ...
+    int64_t panel_spare_min = 8192;    // RFLU_PANEL_SPARE_MIN: ... more than this many rows (and at most 32 * 384)
     int panel_maxg = 32;               // RFLU_PANEL_MAXG: most workgroups of the short-workgroup leaves
     int panel_ballast = 96 * 1024;     // RFLU_PANEL_BALLAST: dynamic LDS asked for by the 64- / 128-row workgroups (keeps them off shared CUs)
     int64_t panel_local_min = 256;     // RFLU_PANEL_LOCAL_MIN

@@ -456,36 +456,51 @@ static int get_pstream(Handle* h, int reserve, hipStream_t* out)
 // Re-checked when the caller's stream changes (rflu_set_stream) or a new masked stream appears.  RFLU_QUEUE_CHECK=0 skips it.
 static int validate_queues(Handle* h)
 {
-    if (!h->tune.queue_check) return RFLU_OK;
+    if (!h->tune.queue_check || h->queue_giveup) return RFLU_OK;
     int created = 0;
     for (int r = 1; r < 8; ++r) created += (h->ustreams[r] != nullptr) + (h->pstreams[r] != nullptr);
-    if (h->queues_ok_count != created) h->queues_ok_streams.clear();
-    for (hipStream_t ok : h->queues_ok_streams)
-        if (ok == h->stream) return RFLU_OK;   // (a host program that alternates between a few streams is checked once per stream)
+    const bool new_masked = h->queues_ok_count != created;   // a masked stream has appeared since the last check: everything is checked again
+    if (!new_masked)
+        for (hipStream_t ok : h->queues_ok_streams)
+            if (ok == h->stream) return RFLU_OK;   // (a host program that alternates between a few streams is checked once per stream)
     if (!h->qprobe_slots) RFLU_HIP(hipMalloc((void**)&h->qprobe_slots, 8 * sizeof(long long)));
     const hipStream_t P = h->stream;
     constexpr int NPROBE = 128;   // the second half is timed (queue_probe_rate)
+    constexpr size_t MAX_PARKED = 16;   // replaced streams stay parked (idle) for the life of the handle: bounded
     double base = 0;
     RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));
     RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));   // the first pass warms the launch path
     const double limit = std::max(2.0 * base, base + 5.0);   // base = the caller's stream against itself (3.1 us); a shared pipe reads 28
+    // a masked stream has to get along with the current caller stream, with the masked streams accepted before it, and with the
+    // caller streams it was accepted next to earlier (so that a host alternating between a few streams does not ping-pong)
     std::vector<hipStream_t> accepted{P};
+    for (hipStream_t ok : h->queues_ok_streams)
+        if (ok != P) accepted.push_back(ok);
     const bool verbose = h->tune.queue_trace != 0;
+    bool unresolved = false;
+    auto worst_next_to = [&](hipStream_t s, double* worst) -> int {
+        *worst = 0;
+        for (hipStream_t a : accepted) {
+            double us = 0;
+            RFLU_TRY(queue_probe_rate(a, s, NPROBE, h->qprobe_slots, &us));
+            *worst = std::max(*worst, us);
+        }
+        return RFLU_OK;
+    };
     auto settle = [&](hipStream_t* slot, int r, bool complement) -> int {
         for (int attempt = 0; attempt < 8; ++attempt) {
             double worst = 0;
-            for (hipStream_t s : accepted) {
-                double us = 0;
-                RFLU_TRY(queue_probe_rate(s, *slot, NPROBE, h->qprobe_slots, &us));
-                worst = std::max(worst, us);
-            }
+            RFLU_TRY(worst_next_to(*slot, &worst));
+            if (worst > limit) RFLU_TRY(worst_next_to(*slot, &worst));   // wall-clock readings: a slow one has to repeat before it counts
             if (verbose)
                 fprintf(stderr, "[rflu] queue check %s[%d] attempt %d: %.1f us per kernel next to the accepted streams (alone %.1f)\n",
                         complement ? "pstream" : "ustream", r, attempt, worst, base);
             if (worst <= limit) break;
-            if (attempt == 7) break;   // keep the last one: never fail a factorization over placement
+            if (attempt == 7 || h->parked_streams.size() >= MAX_PARKED) {   // keep this one: never fail a factorization over placement
+                unresolved = true;
+                break;
+            }
             h->parked_streams.push_back(*slot);
-            h->queues_ok_streams.clear();   // what was accepted next to other caller streams is no longer what is in use
             *slot = nullptr;
             hipStream_t fresh;
             if (complement) RFLU_TRY(get_pstream(h, 32 * r, &fresh));
@@ -499,8 +514,17 @@ static int validate_queues(Handle* h)
         if (h->ustreams[r]) RFLU_TRY(settle(&h->ustreams[r], r, false));
     for (int r = 1; r < 8; ++r)
         if (h->pstreams[r]) RFLU_TRY(settle(&h->pstreams[r], r, true));
+    // more busy caller streams than there are pipes to spare (or a GPU shared with another process, whose load reads like a
+    // conflict): after three checks that could not be settled the placement is taken as it is
+    if (unresolved && ++h->queue_unresolved >= 3) {
+        h->queue_giveup = true;
+        if (verbose) fprintf(stderr, "[rflu] queue check: placement not settled after %d checks, %zu streams parked: no further checks on this handle\n",
+                             h->queue_unresolved, h->parked_streams.size());
+    }
     if (h->queues_ok_streams.size() >= 8) h->queues_ok_streams.erase(h->queues_ok_streams.begin());
-    h->queues_ok_streams.push_back(P);
+    bool known = false;
+    for (hipStream_t ok : h->queues_ok_streams) known = known || ok == P;
+    if (!known) h->queues_ok_streams.push_back(P);
     h->queues_ok_count = 0;
     for (int r = 1; r < 8; ++r) h->queues_ok_count += (h->ustreams[r] != nullptr) + (h->pstreams[r] != nullptr);
     return RFLU_OK;
@@ -1295,6 +1319,9 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
                     }
                 }
             }
+            // the way-back stream as it is NOW: validate_queues (run by the factorization, after C was first taken) may have parked the
+            // stream of this mask and put a fresh one, on a pipe of its own, in its place
+            RFLU_TRY(get_ustream(h, 96, &C));
             const int64_t ldr = workspace_ld(h, n);
             const T* R = static_cast<const T*>(h->work);
             const hipStream_t saved = h->stream;

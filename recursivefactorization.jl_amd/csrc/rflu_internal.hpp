@@ -131,6 +131,8 @@ struct Handle {
     long long* qprobe_slots = nullptr;         // device: 4 stamps of the pipe probe
     std::vector<hipStream_t> queues_ok_streams;   // validate_queues: caller streams the masked streams in use have been checked against
     int queues_ok_count = 0;                      // ... and how many masked streams existed then
+    int queue_unresolved = 0;                     // validate_queues: checks that ended with a conflict it could not settle
+    bool queue_giveup = false;                    // ... three of them: the placement is taken as it is from then on
     hipStream_t pstreams[8] = {};     // pstreams[r]: the complement -- exactly those 32*r CUs (critical path of the update-bound phase)
     bool panel_attr_set[2][2][2] = {};     // [any placement|XCD-local][Float64|Float32][64|128 rows]: dynamic-LDS attribute of the small-workgroup leaves
     hipEvent_t tail_event = nullptr;       // column-major entry: the columns right of the first block column are still being

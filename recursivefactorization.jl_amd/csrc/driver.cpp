@@ -491,7 +491,9 @@ static int validate_queues(Handle* h)
         for (int attempt = 0; attempt < 8; ++attempt) {
             double worst = 0;
             RFLU_TRY(worst_next_to(*slot, &worst));
-            if (worst > limit) RFLU_TRY(worst_next_to(*slot, &worst));   // wall-clock readings: a slow one has to repeat before it counts
+            // wall-clock readings: a marginally slow one has to repeat before it counts; a clear one (a shared pipe reads ~28 us, nine
+            // times the base) is taken at once -- the repeat of a clear reading was seen to come back low and leave the collision in place
+            if (worst > limit && worst < 2.0 * limit) RFLU_TRY(worst_next_to(*slot, &worst));
             if (verbose)
                 fprintf(stderr, "[rflu] queue check %s[%d] attempt %d: %.1f us per kernel next to the accepted streams (alone %.1f)\n",
                         complement ? "pstream" : "ustream", r, attempt, worst, base);

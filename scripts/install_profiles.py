@@ -1,6 +1,6 @@
 """Copy the summaries scripts/collect_profiles.sh and the size/microbench runs left under gpurun_out/ into profiles/ with headers
 that say what they are and which build (hash of the kernel sources) they belong to.
-usage: python scripts/install_profiles.py r03c   (reads gpurun_out/prof_<tag>{,_n4096}/ and gpurun_out/r03/)"""
+usage: python scripts/install_profiles.py r04c   (reads gpurun_out/prof_<tag>{,_n4096}/ and gpurun_out/<first three letters of the tag>/)"""
 import importlib.util, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("_rflu_build", os.path.join(ROOT, "recursivefactorization.jl_amd", "build.py"))
@@ -43,17 +43,17 @@ for n, d in ((16384, f"prof_{tag}"), (4096, f"prof_{tag}_n4096")):
 
 # ---- size table
 rows = []
-for f in sorted(os.listdir(os.path.join(G, "r03"))):
+for f in sorted(os.listdir(os.path.join(G, rnd))):
     if f.startswith("bench_n") and f.endswith(".json"):
-        d = json.loads(rd("r03", f))
+        d = json.loads(rd(rnd, f))
         c = d.get("check") or {}
         res = c.get("residual_fro", "n/a (n > 32768: checked by tests/test_gpu_configs.py)")
         rows.append((d["dtype"], not d["config"].get("pivot", True), d["config"]["n"],
                      f"{d['config']['n']:6d}  {d['dtype']}   {str(d['config'].get('pivot', True)):5s} {d['ms_per_step']:10.3f} {d['value'] / 1e3:9.2f}  {d['frac_of_mfma_peak']:.4f}   {res}"))
 rows.sort()
-dflt = json.loads(rd("r03", "bench_default.json"))
+dflt = json.loads(rd(rnd, "bench_default.json"))
 out = [f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}): python bench.py --size N [--dtype f32] [--nopivot] --steps 5|3 --warmup 1 --no-cpu-baseline --no-extras",
-       "# one MI355X box, one gpurun call (boxes of the pool differ by 3-5 % on the GEMM-bound sizes); the JSON lines are under gpurun_out/r03/ (scratch)",
+       "# one MI355X box, one gpurun call (boxes of the pool differ by 3-5 % on the GEMM-bound sizes); the JSON lines are under gpurun_out/" + rnd + "/ (scratch)",
        "# n      dtype pivot   ms/step   TFLOP/s  frac of dense MFMA peak (78.6 f64 / 157.3 f32)   ||PA-LU||/||A||"]
 out += [r[3] for r in rows]
 out += ["", "# default bench line of the same call (python bench.py --steps 8 --warmup 2), extra keys:"]
@@ -71,7 +71,7 @@ def block(title, *files, keep=""):
     out.append("")
     out.append(title)
     for f in files:
-        p = os.path.join(G, "r03", f)
+        p = os.path.join(G, rnd, f)
         if os.path.exists(p):
             out.extend("# " + l.rstrip() for l in open(p) if l.strip() and "amdgpu.ids" not in l and keep in l)
 block("# bulk GEMM alone (scripts/microbench_gemm_sustained.py: 15872^2 x 512 back to back, f64 then f32; scripts/microbench_gemm_k.py: 15360^2 x K):",
@@ -79,5 +79,6 @@ block("# bulk GEMM alone (scripts/microbench_gemm_sustained.py: 15872^2 x 512 ba
 block("# row interchanges alone (scripts/microbench_laswp.py: 512 interchanges x 16384 columns, C-ABI call = bookkeeping kernel + laswp_kernel):", "laswp_alone.txt")
 block("# host-pointer entry (scripts/microbench_host_entry.py, one caller buffer refilled in place):", "host_entry.txt")
 block("# cooperative leaf alone on the GPU (scripts/panel_bench.py, mode 2 = shipped kernel):", "panel_bench.txt", keep="mode 2")
+block("# solve step ldiv!(F, B) on row-major device factors (scripts/microbench_getrs.py):", "getrs.txt")
 open(os.path.join(P, f"{tag}_sizes.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out[:16]))

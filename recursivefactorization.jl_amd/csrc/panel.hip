@@ -615,7 +615,7 @@ int64_t panel_plan_wgs(const Handle* h, int64_t rows, size_t esize, int pivot)
         const int64_t rpw = esize == 8 ? PANEL_BLOCKED_ROWS_F64 : PANEL_BLOCKED_ROWS_F32;
         return (rows + rpw - 1) / rpw;
     }
-    const int64_t rpw = (pivot && h->panel_local > 0) ? panel_local_rows_per_wg(h, rows) : PANEL_THREADS;
+    const int64_t rpw = (pivot && h->panel_local > 0) ? panel_local_rows_per_wg(h, rows, esize) : PANEL_THREADS;
     return (rows + rpw - 1) / rpw;
 }
 

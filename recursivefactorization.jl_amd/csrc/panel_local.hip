@@ -512,7 +512,7 @@ int panel_local_resident_limit_variant<pl_t, true>(int num_cus);
 // argmax / barrier (scripts/panel_bench.py).  One polling wave reads at most 64 headers and the lookahead schedule keeps 32 or
 // 64 CUs free, so a panel takes the smallest workgroup that keeps it at <= h->tune.panel_maxg workgroups; h->tune.panel_pw
 // (RFLU_PANEL_PW=1|2|4|8) sets a floor.
-int panel_local_rows_per_wg(const Handle* h, int64_t rows)
+int panel_local_rows_per_wg(const Handle* h, int64_t rows, size_t esize)
 {
     if (h->coop_launch) return 512;
     const int floor_pw = h->tune.panel_pw > 0 ? h->tune.panel_pw : 1;
@@ -520,12 +520,15 @@ int panel_local_rows_per_wg(const Handle* h, int64_t rows)
     if (floor_pw <= 1 && (rows + 63) / 64 <= max_g) return 64;
     if (floor_pw <= 2 && (rows + 127) / 128 <= max_g) return 128;
     if (h->tune.panel_rpw > 0) return h->tune.panel_rpw;   // RFLU_PANEL_RPW: experiments
-    if (floor_pw <= 4 && (rows + 255) / 256 <= 32 && !(h->tune.panel_spare && rows > h->tune.panel_spare_min)) return 256;
-    if (h->tune.panel_spare && floor_pw <= 6 && (rows + 383) / 384 <= 32) return 384;   // 6 row waves, the communication wave on a SIMD of its own
+    // 6 row waves, the communication wave on a SIMD of its own: Float64 panels of 8193..12288 rows (Float32, whose row waves have half
+    // the arithmetic, measures 2 % slower with them in the schedule: N=16384 61.4-61.6 -> 62.5-63.3 ms)
+    const bool spare = h->tune.panel_spare && esize == 8 && rows > h->tune.panel_spare_min && floor_pw <= 6 && (rows + 383) / 384 <= 32;
+    if (floor_pw <= 4 && (rows + 255) / 256 <= 32 && !spare) return 256;
+    if (spare) return 384;
     return 512;
 }
 #else
-int panel_local_rows_per_wg(const Handle* h, int64_t rows);
+int panel_local_rows_per_wg(const Handle* h, int64_t rows, size_t esize);
 #endif
 
 // Launch the leaf on the blocks b with b % stride == sel of a grid of G*stride workgroups.  local != 0: plain-store
@@ -542,7 +545,7 @@ int launch_panel_local(Handle* h, const PanelArgs<T>& p0, int stride, int sel, i
     la.poll_adapt = h->tune.poll_adapt;
     if (p0.w != NB) { set_error("launch_panel_local: full leaves only (w = %d)", p0.w); return RFLU_ERR_ARG; }
     const int64_t rows = (int64_t)p0.m - p0.r0;
-    int rpw = local ? (((rows + 255) / 256 <= 32 && !h->coop_launch) ? 256 : 512) : panel_local_rows_per_wg(h, rows);
+    int rpw = local ? (((rows + 255) / 256 <= 32 && !h->coop_launch) ? 256 : 512) : panel_local_rows_per_wg(h, rows, sizeof(T));
     // XCD-local: at most 16 participants (the other 7/8 of the launch have to find a home too), so the short workgroups whose
     // per-column chain is shorter serve panels of <= 1024 / 2048 rows (N=2048 5.38 -> 5.11 ms, N=4096 11.01 -> 10.74, N=8192 25.47 -> 25.2)
     if (local && !h->coop_launch) {

@@ -243,7 +243,7 @@ int ensure_bookkeeping(Handle* h, int64_t rows);
 int ensure_buffer(void** ptr, size_t* cap, size_t need);  // grow-only device buffer (hipFree + hipMalloc)
 
 // ---- kernel launchers (each returns an rflu_status); all pointers are device pointers in R layout -----------------------
-int panel_local_rows_per_wg(const Handle* h, int64_t rows);   // panel_local.hip: rows per workgroup of a pivoted leaf
+int panel_local_rows_per_wg(const Handle* h, int64_t rows, size_t esize);   // panel_local.hip: rows per workgroup of a pivoted leaf
 // panel.hip: does a full pivoted leaf of `rows` rows go to the sub-panel kernel (panel_blocked.hip), and the workgroups the leaf
 // kernel of launch_panel's choice takes (what a schedule has to keep free)
 bool panel_use_blocked(const Handle* h, int64_t rows, size_t esize);

@@ -14,7 +14,10 @@ python scripts/rocpd_summary.py $DB > $OUT/kernel_stats.txt
 python scripts/rocpd_queues.py $DB 1 >> $OUT/kernel_stats.txt
 echo "# the profiled single-stream pass (4th factorization of the run): bench.py's roofline.avg_launch_ms is the gemm_sub_kernel average of THIS pass" >> $OUT/kernel_stats.txt
 python scripts/rocpd_queues.py $DB 3 >> $OUT/kernel_stats.txt
-CMD1="python bench.py --size $SIZE --steps 1 --warmup 0 --no-cpu-baseline --no-check --no-extras"
+# counter collection runs ONE kernel at a time across all queues: device-side gates cannot make progress, so the counter passes ask
+# for the schedule whose cross-stream edges are hipEvents (same kernels, same shapes for the bulk GEMM)
+export RFLU_SCHEDULE_PMC=events
+CMD1="env RFLU_SCHEDULE=events python bench.py --size $SIZE --steps 1 --warmup 0 --no-cpu-baseline --no-check --no-extras"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -- $CMD1 > /dev/null 2>$OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -- $CMD1 > /dev/null 2>$OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES -f csv -d $OUT/pmc_mfma -- $CMD1 > /dev/null 2>$OUT/pmc_mfma.err

@@ -522,7 +522,10 @@ int panel_local_rows_per_wg(const Handle* h, int64_t rows, size_t esize)
     if (h->tune.panel_rpw > 0) return h->tune.panel_rpw;   // RFLU_PANEL_RPW: experiments
     // 6 row waves, the communication wave on a SIMD of its own: Float64 panels of 8193..12288 rows (Float32, whose row waves have half
     // the arithmetic, measures 2 % slower with them in the schedule: N=16384 61.4-61.6 -> 62.5-63.3 ms)
-    const bool spare = h->tune.panel_spare && esize == 8 && rows > h->tune.panel_spare_min && floor_pw <= 6 && (rows + 383) / 384 <= 32;
+    // ... and of 16385..24576 rows (43..64 workgroups: the same 64-CU reservation the 512-row workgroups need there)
+    const int64_t g384 = (rows + 383) / 384, g512 = (rows + 511) / 512;
+    const bool spare = h->tune.panel_spare && esize == 8 && rows > h->tune.panel_spare_min && floor_pw <= 6 && g384 <= 64 &&
+                       (g384 + 31) / 32 == (g512 + 31) / 32;
     if (floor_pw <= 4 && (rows + 255) / 256 <= 32 && !spare) return 256;
     if (spare) return 384;
     return 512;

@@ -471,11 +471,12 @@ static int validate_queues(Handle* h)
     RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));
     RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));   // the first pass warms the launch path
     const double limit = std::max(2.0 * base, base + 5.0);   // base = the caller's stream against itself (3.1 us); a shared pipe reads 28
-    // a masked stream has to get along with the current caller stream, with the masked streams accepted before it, and with the
-    // caller streams it was accepted next to earlier (so that a host alternating between a few streams does not ping-pong)
+    // a masked stream has to get along with the current caller stream and with the masked streams accepted before it.  (Not with the
+    // caller streams it was accepted next to earlier: those are idle while this one is in use, and with two caller streams + three
+    // masked streams there are more queues than pipes -- asking for that left the host entry's way-back stream on a shared pipe:
+    // 120 -> 145 ms host to host.  A host that alternates between caller streams gets a new check when a stream had to be
+    // replaced for the other one; the cap on parked streams and the give-up rule below bound what that can cost.)
     std::vector<hipStream_t> accepted{P};
-    for (hipStream_t ok : h->queues_ok_streams)
-        if (ok != P) accepted.push_back(ok);
     const bool verbose = h->tune.queue_trace != 0;
     bool unresolved = false;
     auto worst_next_to = [&](hipStream_t s, double* worst) -> int {
@@ -503,6 +504,7 @@ static int validate_queues(Handle* h)
                 break;
             }
             h->parked_streams.push_back(*slot);
+            h->queues_ok_streams.clear();   // what was accepted next to other caller streams is no longer what is in use
             *slot = nullptr;
             hipStream_t fresh;
             if (complement) RFLU_TRY(get_pstream(h, 32 * r, &fresh));

@@ -4,8 +4,11 @@ import sqlite3, re, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 which, first, count = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 rows = cur.execute("select name, start, end, queue_id, grid_x, workgroup_x from kernels order by start").fetchall()
-tr = [i for i, r in enumerate(rows) if 'transpose' in r[0]]
-seg = rows[tr[2 * which]:tr[2 * which + 1] + 1]
+fills = [i for i, r in enumerate(rows) if 'fill_uniform' in r[0]]   # bench.py refills the input before every lu!
+a0 = fills[which] + 1
+b0 = fills[which + 1] - 1 if which + 1 < len(fills) else len(rows) - 1
+while 'transpose' not in rows[b0][0]: b0 -= 1
+seg = rows[a0:b0 + 1]
 short = lambda n: re.sub(r"<.*", "", re.sub(r"\(.*", "", n.replace("void rflu::", "")))
 import collections
 qP = collections.Counter(r[3] for r in seg if 'panel_pivot' in r[0]).most_common(1)[0][0]   # the critical-path queue

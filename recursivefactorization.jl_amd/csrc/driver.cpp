@@ -86,6 +86,7 @@ void Tune::load_env()
     env_flag("RFLU_GATE_TRACE", gate_trace);
     if (const char* e = env_str("RFLU_SCHEDULE")) schedule_events = strcmp(e, "events") == 0;
     env_flag("RFLU_TIME_ENQUEUE", time_enqueue);
+    env_get("RFLU_SWAP_LATE", swap_late);
     env_get("RFLU_TAIL_OVERLAP", tail_overlap);
     env_get("RFLU_HOST_EARLY_OUT", host_early_out);
     env_flag("RFLU_HOST_TRACE", host_trace);
@@ -680,7 +681,10 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         // the panel that will run next to this block column's update is panel b+1
         const int64_t rows_next = m - je;
         const int64_t g_next = panel_wgs(h, rows_next, f.pivot, sizeof(T));
-        const int reserve = std::max<int>(min_reserve, int((std::max<int64_t>(g_next, 1) + 31) / 32 * 32));
+        int reserve = std::max<int>(min_reserve, int((std::max<int64_t>(g_next, 1) + 31) / 32 * 32));
+        // RFLU_SWAP_LATE=2 (default): the last block column in front of the leaf-wise part sends its update to the 192-CU stream, so
+        // that the 224-CU stream is free to be the side stream of the first leaf-wise block column already (factor_leafwise, swap_mode)
+        if (h->tune.swap_late == 2 && reserve == 32 && last_here && b_end < nid) reserve = 64;
         if (reserve > std::min(max_reserve, 224)) {
             // the next panel needs (almost) the whole GPU: run this block column on one stream
             if (uend_prev >= 0) {
@@ -847,7 +851,17 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     // leaf needs the side stream (2.4 ms stall), and moving that update to the 192-CU stream costs what the swap wins (N=16384
     // 85.1 vs 85.3 ms, N=12288 49.0 vs 48.8): there the update keeps 224 CUs and the side stream takes the 192-CU stream.
     // (Float32 at N=16384 is leaf-wise from block column 0 as well, but there the update still needs its 224 CUs: 63.9 vs 62.1 ms.)
-    const bool swap_su = h->tune.swap_su >= 0 ? h->tune.swap_su != 0 : (b_begin == 0 && m <= 8192);
+    // Round 4: swapped after a lookahead part too (swap_mode 2): every U(b) of this function goes to the 192-CU stream and the side
+    // stream is the 224-CU one -- from the first leaf-wise block column on when the lookahead part sent its LAST update to the 192-CU
+    // stream as well (RFLU_SWAP_LATE=2, default: N=16384 79.1 -> 77.75 ms, N=12288 45.9 -> 45.7), from the second one on when it did
+    // not (RFLU_SWAP_LATE=1: 78.0; the first block column then keeps the 192-CU side stream while the 224-CU stream drains).  What it is for
+    // (scripts/rocpd_timeline.py, scripts/gate_trace.py): a bulk GEMM that STARTS fills every workgroup slot its mask allows at once,
+    // and its tiles then finish in rounds of ~130 us -- a side stream confined to the same CUs gets its three small kernels per leaf
+    // placed one round boundary at a time (96 + 128 + 211 us instead of 6 + 12 + 30) and the critical path stalls on gate 1 at the
+    // third / fourth leaf of every block column.
+    const int swap_mode = h->tune.swap_su >= 0 ? h->tune.swap_su : ((b_begin == 0 && m <= 8192) ? 1 : (b_begin > 0 && h->tune.swap_late) ? 2 : 0);
+    auto swap_s = [&](int64_t b) { return swap_mode == 1 || (swap_mode == 2 && (b > b_begin || h->tune.swap_late == 2)); };   // side stream of block column b on the 224-CU stream
+    const bool swap_u_all = swap_mode == 1 || swap_mode == 2;                                     // every U(b) on the 192-CU stream
     const bool fold = h->tune.gate_fold != 0 && !h->tune.gate_trace;
     const int64_t confine_rows = h->tune.confine_rows;
     auto reserve_for = [&](int64_t rows) {
@@ -910,7 +924,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         // and a taller matrix has already used it for its first block columns -- one queue less to place (validate_queues).
         if (res != 32) { set_error("factor_leafwise: panel of %lld rows needs more than 32 CUs", (long long)(m - j0)); return RFLU_ERR_ARG; }
         hipStream_t S;
-        RFLU_TRY(get_ustream(h, swap_su ? 32 : 64, &S));
+        RFLU_TRY(get_ustream(h, swap_s(b) ? 32 : 64, &S));
         {   // the critical path runs on the reserved CUs while the update stream is the bottleneck (see get_pstream)
             hipStream_t to = userS;
             if (m - j0 >= confine_rows && res == 32) RFLU_TRY(get_pstream(h, res, &to));
@@ -950,7 +964,10 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             if (rc == RFLU_OK && i == 0 && S != Sprev && g > gfirst) rc = launch_gate_wait(h, h->gate_ptr[2], val(g - 1));
             if (i == 0 && b > 0) {
                 // the next block column holds U(b-1)'s update only after evU1[b-1]; the critical path needs this block
-                // column's part first, so the leaf is applied in two pieces with a gate of its own in between
+                // column's part first, so the leaf is applied in two pieces with a gate of its own in between.
+                // (Round 4 tried leaving the next block column's part of the first 1..6 leaves to a later leaf, so that the in-order
+                // side stream does not sit on the event with the own parts of the next leaves queued behind it: no gain, N=16384
+                // 78.2-78.9 vs 78.7-79.1 ms -- the event is not what the side stream waits for, see swap_mode above.)
                 if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, la1, bend, true);
                 h->stream = S;
                 if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g), stamp(1, g));
@@ -972,7 +989,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         Sprev = S;
         // ---- U(b): everything right of block column b+1, and the interchanges nobody needed until now ----
         hipStream_t U;
-        RFLU_TRY(get_ustream(h, swap_su ? 64 : reserve_for(m - je), &U));
+        RFLU_TRY(get_ustream(h, swap_u_all ? 64 : reserve_for(m - je), &U));
         const int64_t glast = g0 + nl - 1;
         {
             h->stream = U;

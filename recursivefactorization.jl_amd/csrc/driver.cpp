@@ -87,6 +87,7 @@ void Tune::load_env()
     if (const char* e = env_str("RFLU_SCHEDULE")) schedule_events = strcmp(e, "events") == 0;
     env_flag("RFLU_TIME_ENQUEUE", time_enqueue);
     env_get("RFLU_SWAP_LATE", swap_late);
+    env_get("RFLU_SWAP_ROWS", swap_rows);
     env_get("RFLU_TAIL_OVERLAP", tail_overlap);
     env_get("RFLU_HOST_EARLY_OUT", host_early_out);
     env_flag("RFLU_HOST_TRACE", host_trace);
@@ -682,9 +683,9 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         const int64_t rows_next = m - je;
         const int64_t g_next = panel_wgs(h, rows_next, f.pivot, sizeof(T));
         int reserve = std::max<int>(min_reserve, int((std::max<int64_t>(g_next, 1) + 31) / 32 * 32));
-        // RFLU_SWAP_LATE=2 (default): the last block column in front of the leaf-wise part sends its update to the 192-CU stream, so
-        // that the 224-CU stream is free to be the side stream of the first leaf-wise block column already (factor_leafwise, swap_mode)
-        if (h->tune.swap_late == 2 && reserve == 32 && last_here && b_end < nid) reserve = 64;
+        // RFLU_SWAP_LATE (default on): the last block column in front of a leaf-wise part that starts swapped sends its update to the
+        // 192-CU stream, so that the 224-CU stream is free to be the side stream of the first leaf-wise block column (factor_leafwise)
+        if (h->tune.swap_late && reserve == 32 && last_here && b_end < nid && rows_next <= h->tune.swap_rows) reserve = 64;
         if (reserve > std::min(max_reserve, 224)) {
             // the next panel needs (almost) the whole GPU: run this block column on one stream
             if (uend_prev >= 0) {
@@ -851,17 +852,18 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     // leaf needs the side stream (2.4 ms stall), and moving that update to the 192-CU stream costs what the swap wins (N=16384
     // 85.1 vs 85.3 ms, N=12288 49.0 vs 48.8): there the update keeps 224 CUs and the side stream takes the 192-CU stream.
     // (Float32 at N=16384 is leaf-wise from block column 0 as well, but there the update still needs its 224 CUs: 63.9 vs 62.1 ms.)
-    // Round 4: swapped after a lookahead part too (swap_mode 2): every U(b) of this function goes to the 192-CU stream and the side
-    // stream is the 224-CU one -- from the first leaf-wise block column on when the lookahead part sent its LAST update to the 192-CU
-    // stream as well (RFLU_SWAP_LATE=2, default: N=16384 79.1 -> 77.75 ms, N=12288 45.9 -> 45.7), from the second one on when it did
-    // not (RFLU_SWAP_LATE=1: 78.0; the first block column then keeps the 192-CU side stream while the 224-CU stream drains).  What it is for
-    // (scripts/rocpd_timeline.py, scripts/gate_trace.py): a bulk GEMM that STARTS fills every workgroup slot its mask allows at once,
-    // and its tiles then finish in rounds of ~130 us -- a side stream confined to the same CUs gets its three small kernels per leaf
-    // placed one round boundary at a time (96 + 128 + 211 us instead of 6 + 12 + 30) and the critical path stalls on gate 1 at the
-    // third / fourth leaf of every block column.
-    const int swap_mode = h->tune.swap_su >= 0 ? h->tune.swap_su : ((b_begin == 0 && m <= 8192) ? 1 : (b_begin > 0 && h->tune.swap_late) ? 2 : 0);
-    auto swap_s = [&](int64_t b) { return swap_mode == 1 || (swap_mode == 2 && (b > b_begin || h->tune.swap_late == 2)); };   // side stream of block column b on the 224-CU stream
-    const bool swap_u_all = swap_mode == 1 || swap_mode == 2;                                     // every U(b) on the 192-CU stream
+    // Round 4: swapped from the first panel of at most swap_rows (8192) rows on, wherever that is (swap_mode 2): from block column
+    // bs on the side stream is the 224-CU stream, and from U(bs-1) on every update goes to the 192-CU one -- the last update in front
+    // of the swap too (it is factor_lookahead's when bs is the first leaf-wise block column), so that the 224-CU stream is idle when
+    // the side stream moves there.  N=16384 79.1 -> 77.75 ms (swapped one block column later, without moving that update: 78.0),
+    // N=12288 45.9 -> 45.7.  What it is for (scripts/rocpd_timeline.py, scripts/gate_trace.py): a bulk GEMM that STARTS fills every
+    // workgroup slot its mask allows at once, and its tiles then finish in rounds of ~130 us -- a side stream confined to the same
+    // CUs gets its three small kernels per leaf placed one round boundary at a time (96 + 128 + 211 us instead of 6 + 12 + 30) and
+    // the critical path stalls on gate 1 at the third / fourth leaf of every block column (200..500 us each, 3 ms in all).
+    const int swap_mode = h->tune.swap_su >= 0 ? h->tune.swap_su : ((b_begin == 0 && m <= 8192) ? 1 : h->tune.swap_late ? 2 : 0);
+    const int64_t bs = std::max<int64_t>(b_begin, (std::max<int64_t>(m - h->tune.swap_rows, 0) + W - 1) / W);   // first swapped block column
+    auto swap_s = [&](int64_t b) { return swap_mode == 1 || (swap_mode == 2 && b >= bs); };       // side stream of block column b on the 224-CU stream
+    auto swap_u = [&](int64_t b) { return swap_mode == 1 || (swap_mode == 2 && b + 1 >= bs); };   // U(b) on the 192-CU stream
     const bool fold = h->tune.gate_fold != 0 && !h->tune.gate_trace;
     const int64_t confine_rows = h->tune.confine_rows;
     auto reserve_for = [&](int64_t rows) {
@@ -989,7 +991,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         Sprev = S;
         // ---- U(b): everything right of block column b+1, and the interchanges nobody needed until now ----
         hipStream_t U;
-        RFLU_TRY(get_ustream(h, swap_u_all ? 64 : reserve_for(m - je), &U));
+        RFLU_TRY(get_ustream(h, swap_u(b) ? 64 : reserve_for(m - je), &U));
         const int64_t glast = g0 + nl - 1;
         {
             h->stream = U;

@@ -97,7 +97,8 @@ struct Tune {
     // host-pointer entry
     int64_t host_early_out = 512;      // RFLU_HOST_EARLY_OUT
     int host_trace = 0;                // RFLU_HOST_TRACE
-    int swap_late = 2;                 // RFLU_SWAP_LATE: leaf-wise part behind a lookahead part: 1 = side stream on the 224-CU stream from its second block column on, 2 = from its first (the last lookahead update goes to the 192-CU stream), 0 = round 3's assignment
+    int swap_late = 1;                 // RFLU_SWAP_LATE: leaf-wise schedule: side stream on the 224-CU stream (updates on the 192-CU one) from the first panel of at most swap_rows rows on, also behind a lookahead part (0: round 3's assignment)
+    int64_t swap_rows = 8192;          // RFLU_SWAP_ROWS
     int host_threads = 8;              // RFLU_HOST_THREADS
     // multi-GPU
     int64_t mgpu_big_reserve = 128;    // RFLU_MGPU_BIG_RESERVE

@@ -16,9 +16,9 @@ def stats_header(n):
     return (f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}, profiles/gemm_traffic.json) -- rocprofv3 --kernel-trace --stats -- python bench.py --size {n} --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-extras\n"
             "# (3 timed factorizations incl. warm-up in the shipped schedule + 1 profiled single-stream pass; Float64, one MI355X; scripts/collect_profiles.sh)\n"
             "# first table: all kernels of the run (scripts/rocpd_summary.py); second: one timed factorization split by HIP queue\n"
-            "# (scripts/rocpd_queues.py): the caller's stream = critical path, the CU-masked update stream, and -- from the first panel of\n"
-            "# <= 8192 rows on -- the side stream of the leaf-wise schedule.  gate_wait_kernel time is waiting, not work; laswp_kernel on the\n"
-            "# caller's stream includes the folded gate wait.\n"
+            "# (scripts/rocpd_queues.py): the caller's stream = critical path; the 224-CU stream (updates of the lookahead part, then -- from the\n"
+            "# first panel of <= 8192 rows on -- the side stream of the leaf-wise schedule); the 192-CU stream (the updates from the last lookahead\n"
+            "# block column on).  gate_wait_kernel time is waiting, not work; laswp_kernel on the caller's stream includes the folded gate wait.\n"
             "# third: the profiled single-stream pass: bench.py's roofline.avg_launch_ms is the gemm_sub_kernel average of THAT pass.\n")
 
 def pmc_header(n):
@@ -38,7 +38,8 @@ for n, d in ((16384, f"prof_{tag}"), (4096, f"prof_{tag}_n4096")):
         open(os.path.join(P, f"{tag}_n{n}_blocks.txt"), "w").write(
             f"# round {int(rnd[1:])}, shipped build -- same rocprofv3 --kernel-trace run as {tag}_n{n}_kernel_stats.txt, one timed factorization\n"
             "# (scripts/rocpd_blocks.py): when every block column's first leaf starts on the critical-path queue, and how busy each queue is\n"
-            "# per 5 ms window.  Queue 1 = caller's stream (chain), queue 3 = update stream (224 CUs), queue 4 = side stream of the leaf-wise part.\n"
+            "# per 5 ms window.  Queue 1 = caller's stream (chain); queue 3 = the 224-CU stream: update stream of the lookahead part, side stream of the\n"
+            "# leaf-wise part; queue 4 = the 192-CU stream: the updates from the last lookahead block column on (round 4, DESIGN.md section 3.11).\n"
             + rd(d, "blocks.txt"))
 
 # ---- size table

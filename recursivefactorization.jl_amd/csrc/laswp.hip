@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(64 * LW_WAVES) laswp_kernel(T* __restrict__ R,
         const int64_t i = (int64_t)blockIdx.x - swap_blocks;
         if (inv_nb > 0 && i < inv_cnt) {   // workgroup-uniform
             T* sL = reinterpret_cast<T*>(lw_smem);
-            diag_inv_block4<T>(inv_nb, inv_L + i * (NB * ld + NB), ld, inv_out + i * NB * NB, sL, sL + NB * NB, threadIdx.x);
+            diag_inv_block16<T>(inv_nb, inv_L + i * (NB * ld + NB), ld, inv_out + i * NB * NB, sL, sL + NB * NB, threadIdx.x);
         }
     } else {
         const int64_t strip = (int64_t)blockIdx.x * LW_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -123,4 +123,109 @@ __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lb
     }
 }
 
+
+// ---- round 4: the same inverse with three levels of blocking and the products on the matrix cores --------------------------------
+// The interchange launch behind every leaf ends when its inverting workgroup does, and that workgroup was the long pole: 10 us
+// against 3 us for the interchanges (stamps inside the launch; leaving the inverse out -- wrong factors, right timing -- N=16384
+// 77.2 -> 74.9 ms, N=8192 25.3 -> 24.5).  Here the diagonal is inverted in 16x16 blocks (four waves side by side, one lane per
+// column: 120 multiply-adds instead of 496), and the two levels above it, inv([A 0; B C]) = [inv(A) 0; -inv(C) B inv(A)  inv(C)],
+// are 16x16x16 and 32x32x32 products on v_mfma_*_16x16x4 with operands straight from LDS (one tile per wave), on a bank-conflict
+// free image (below).  Now 6.6 us: 2.0 waiting for the block from memory, 1.8 the 16x16 substitutions, 2.0 the four product steps,
+// 0.8 the store (N=16384 77.2 -> 76.9 ms, N=8192 25.3 -> 25.0, N=4096 10.35 -> 10.15).  Unit lower triangle only (the non-unit
+// upper variant keeps diag_inv_block4).
+template <typename T>
+struct InvMfma;
+template <>
+struct InvMfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct InvMfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+// LDS image of a 64x64 block with the columns of row i rotated by i: element (i, j) at i*NB + ((j + i) & 63).  With the plain
+// row-major image (row pitch 512 bytes = a whole number of bank cycles) every access that walks down a column -- the A operand of
+// the products, the thread-per-row load and store of the block -- puts all its lanes on ONE bank pair: the load and the store of the
+// block were 64-way conflicted, the operand reads 16-way (stamps: 1.1 us per 32x32x32 product, 10 us for the whole inverse).
+#define RFLU_INV_IDX(i, j) ((i) * NB + ((((j) + (i))) & (NB - 1)))
+
+// one 16x16 tile of  C = (NEG ? -1 : 1) * A(16 x K) * B(K x 16): A = rows ar.., columns ac.. of MA, B = rows br.., columns bc.. of MB,
+// C = rows cr.., columns cc.. of MC (rotated images); the calling wave only
+template <typename T, int K, bool NEG>
+__device__ __forceinline__ void inv_tile_prod(const T* MA, int ar, int ac, const T* MB, int br, int bc, T* MC, int cr, int cc, int lane)
+{
+    typename InvMfma<T>::acc_t acc = {T(0), T(0), T(0), T(0)};
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int k0 = 0; k0 < K; k0 += 4)
+        acc = InvMfma<T>::run(MA[RFLU_INV_IDX(ar + li, ac + k0 + lk)], MB[RFLU_INV_IDX(br + k0 + lk, bc + li)], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) MC[RFLU_INV_IDX(cr + InvMfma<T>::crow(lane, r), cc + li)] = NEG ? -acc[r] : acc[r];
+}
+
+// sL, sX: NB*NB elements of LDS each.  All 256 threads of the workgroup must call this.
+template <typename T>
+__device__ __forceinline__ void diag_inv_block16(int nb, const T* __restrict__ Lblk, int64_t ldl, T* __restrict__ Linv, T* sL, T* sX,
+                                                 int tid)
+{
+    constexpr int Q = NB / 4, H = NB / 2;
+    const int wave = tid >> 6, lane = tid & 63;
+    {   // strictly lower part of the block into sL (zero elsewhere, also outside nb: the padding inverts to the identity)
+        const int i = tid >> 2, c0 = (tid & 3) * 16;
+        T v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = (i < nb && c0 + e < i) ? Lblk[(int64_t)i * ldl + c0 + e] : T(0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sL[RFLU_INV_IDX(i, c0 + e)] = v[e];
+            sX[RFLU_INV_IDX(i, c0 + e)] = T(0);
+        }
+    }
+    __syncthreads();
+    if (lane < Q) {   // the four 16x16 diagonal blocks: wave w inverts block w, lane j owns column j of the inverse
+        const int o = wave * Q;
+        T x[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) x[i] = (i == lane) ? T(1) : T(0);
+#pragma unroll
+        for (int i = 1; i < Q; ++i) {
+            T acc[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+            for (int k = 0; k < i; ++k) acc[k & 3] += sL[RFLU_INV_IDX(o + i, o + k)] * x[k];
+            x[i] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) sX[RFLU_INV_IDX(o + i, o + lane)] = x[i];
+    }
+    __syncthreads();
+    // the two 32x32 diagonal blocks p = 0, 1 (waves 0, 1):  T = B inv(A), parked in the zero quadrant next to A inside sL ...
+    if (wave < 2) {
+        const int o = wave * H;
+        inv_tile_prod<T, Q, false>(sL, o + Q, o, sX, o, o, sL, o, o + Q, lane);
+    }
+    __syncthreads();
+    if (wave < 2) {   // ... and -inv(C) T into the inverse
+        const int o = wave * H;
+        inv_tile_prod<T, Q, true>(sX, o + Q, o + Q, sL, o, o + Q, sX, o + Q, o, lane);
+    }
+    __syncthreads();
+    // the 64x64 level, one 16x16 tile per wave: T = B inv(A) (B = rows 32.., columns 0..31 of L; parked in the zero quadrant of sL)
+    const int ti = (wave >> 1) * Q, tj = (wave & 1) * Q;
+    inv_tile_prod<T, H, false>(sL, H + ti, 0, sX, 0, tj, sL, ti, H + tj, lane);
+    __syncthreads();
+    inv_tile_prod<T, H, true>(sX, H + ti, H, sL, 0, H + tj, sX, H + ti, tj, lane);   // lower left quadrant of the inverse: -inv(C) T
+    __syncthreads();
+    {
+        const int i = tid >> 2, c0 = (tid & 3) * 16;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Linv[i * NB + c0 + e] = sX[RFLU_INV_IDX(i, c0 + e)];
+    }
+}
+#undef RFLU_INV_IDX
+
 }  // namespace rflu

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) diag_inv_kernel(int n, const T* __restric
     __shared__ T sX[NB * NB];
     const int b = blockIdx.x;
     const int nb = min(NB, n - b * NB);
-    diag_inv_block4<T>(nb, L + (int64_t)b * NB * ldl + b * NB, ldl, Linv_all + (size_t)b * NB * NB, sL, sX, threadIdx.x);
+    diag_inv_block16<T>(nb, L + (int64_t)b * NB * ldl + b * NB, ldl, Linv_all + (size_t)b * NB * NB, sL, sX, threadIdx.x);
 }
 
 // invert every 64x64 diagonal block of the n x n unit lower triangle L into Linv[0 .. ceil(n/64))

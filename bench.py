@@ -332,7 +332,9 @@ def main():
     if True:
         regenerate()
         barrier()
-        h.profile_enable(True)
+        # mode 3: the single-stream blocked schedule with an event pair around every launch and no host wait in between (mode 1 waits
+        # for every launch: the GPU idles ~20 us behind each kernel and its power management answers with a lower clock)
+        h.profile_enable(3 if single else True)
         if single:
             step()
         elif job is not None:
@@ -375,8 +377,8 @@ def main():
                     "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                     "flops_per_launch": g["work"] / g["launches"],
                     "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
-                    "note": ("all gemm_sub_kernel launches of one profiled factorization (single-stream blocked schedule, HIP "
-                             "events on the launch stream); " + traffic_note) if single else
+                    "note": ("all gemm_sub_kernel launches of one profiled factorization (single-stream blocked schedule, a HIP "
+                             "event pair around every launch on the launch stream, read after the factorization); " + traffic_note) if single else
                             ("rank 0's gemm_sub_kernel launches of one profiled single-stream factorization (per-GPU figure)"
                              if job is not None else
                              "per-GPU kernel: gemm_sub_kernel launches of one profiled single-GPU factorization of the 1-GPU "

@@ -222,6 +222,9 @@ int rflu_mgpu_fill_uniform_f32(rflu_mgpu_t mgpu, int64_t n, float* const* slabs_
  * enable = 2: in-schedule mode -- event pairs are recorded on whatever stream a launch goes to and resolved when the
  *             timers are read; the default two-stream lookahead schedule is left untouched (what a kernel achieves next
  *             to the other stream's work);
+ * enable = 3: the single-stream blocked schedule of mode 1 with the event pairs of mode 2: nothing is waited for between the
+ *             launches, so the GPU does not go idle (and its power management does not lower the clock) behind every kernel --
+ *             each kernel alone on the GPU at the clock of a busy GPU (bench.py's roofline pass);
  * enable = 0: off.  Enabling resets the timers.  rflu_profile_get returns accumulated milliseconds, launch count and the
  * algorithmic work (flops for GEMM/TRSM/PANEL, bytes for LASWP/TRANSPOSE) of class k since enabling. */
 int rflu_profile_enable(rflu_handle_t handle, int enable);

@@ -1062,7 +1062,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     // first access to those columns is; every other path waits for it here
     hipEvent_t tail = h->tail_event;
     h->tail_event = nullptr;
-    const bool two_stream = !(blocksize < 0 || blocksize >= mn) && !h->prof && h->num_cus == 256;
+    const bool two_stream = !(blocksize < 0 || blocksize >= mn) && !(h->prof || h->prof_one_stream) && h->num_cus == 256;
     if (tail && !two_stream) {
         RFLU_HIP(hipStreamWaitEvent(h->stream, tail, 0));
         tail = nullptr;
@@ -1070,7 +1070,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
     if (blocksize < 0 || blocksize >= mn) {
         h->last_path = RFLU_PATH_HIP_RECURSIVE;
         RFLU_TRY(f.rec(0, mn));
-    } else if (!h->prof && h->num_cus == 256) {   // the CU reservation of the two-stream schedule is laid out for 8 x 32 CUs
+    } else if (!(h->prof || h->prof_one_stream) && h->num_cus == 256) {   // the CU reservation of the two-stream schedule is laid out for 8 x 32 CUs
         h->last_path = RFLU_PATH_HIP_LOOKAHEAD;
         // tall block columns (update-bound): factor_lookahead; from the first panel of at most lw_rows rows on: factor_leafwise.
         // RFLU_LEAFWISE=0 keeps the lookahead schedule to the end.
@@ -1173,7 +1173,7 @@ static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int6
     int64_t W0 = blocksize == 0 ? default_blocksize(mn) : blocksize;
     W0 = W0 > 0 ? round_up(W0, NB) : 0;
     const bool tail_overlap = h->tune.tail_overlap != 0;
-    if (tail_overlap && !h->prof && h->num_cus == 256 && mn >= 12288 && W0 > 0 && W0 < mn && n - W0 >= 4096) {
+    if (tail_overlap && !(h->prof || h->prof_one_stream) && h->num_cus == 256 && mn >= 12288 && W0 > 0 && W0 < mn && n - W0 >= 4096) {
         if (!h->tail_event_obj) {
             RFLU_HIP(hipEventCreateWithFlags(&h->tail_event_obj, hipEventDisableTiming));
             RFLU_HIP(hipEventCreateWithFlags(&h->tail_fork_obj, hipEventDisableTiming));
@@ -1254,7 +1254,7 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
     // RFLU_HOST_EARLY_OUT=0: the round-2 sequence (everything after the factorization).
     const int64_t chunk = h->tune.host_early_out;
     const int64_t W0 = blocksize == 0 ? default_blocksize(mn) : blocksize;
-    const bool early = chunk >= 64 && !h->prof && h->num_cus == 256 && mn >= 8192 && W0 > 0 && W0 < mn;
+    const bool early = chunk >= 64 && !(h->prof || h->prof_one_stream) && h->num_cus == 256 && mn >= 8192 && W0 > 0 && W0 < mn;
     struct Mark { int64_t r1; std::vector<hipEvent_t> ev; };
     std::vector<Mark> marks;
     size_t ev_used = 0;
@@ -2296,7 +2296,8 @@ int rflu_profile_enable(rflu_handle_t handle, int enable)
     CHECK_HANDLE(handle);
     Handle* h = H(handle);
     h->prof = enable == 1;
-    h->prof_async = enable == 2;
+    h->prof_async = enable == 2 || enable == 3;
+    h->prof_one_stream = enable == 3;
     for (int k = 0; k < RFLU_K_COUNT; ++k) h->slots[k] = ProfSlot();
     for (auto& r : h->async_recs) { h->async_pool.push_back(r.a); h->async_pool.push_back(r.b); }
     h->async_recs.clear();

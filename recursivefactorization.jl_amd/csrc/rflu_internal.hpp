@@ -195,6 +195,8 @@ struct Handle {
     // timers
     bool prof = false;           // synchronous mode: every launch bracketed and waited for (switches to the one-stream schedule)
     bool prof_async = false;     // in-schedule mode: event pairs recorded on the launch streams, resolved by profile_get
+    bool prof_one_stream = false;   // mode 3: the one-stream schedule of the synchronous mode with the event pairs of the in-schedule mode
+                                    // (nothing waited for between launches: the GPU does not idle -- and drop its clock -- behind every kernel)
     ProfSlot slots[RFLU_K_COUNT];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct AsyncRec { int k; hipEvent_t a, b; double work, bytes; };

@@ -76,7 +76,8 @@ template int launch_trsm_base<float>(Handle*, int64_t, int64_t, const float*, in
 // The inverse of a unit lower triangular block with |l_ij| <= 1 (partial pivoting) is what MAGMA/rocBLAS-style TRSMs
 // use for their diagonal blocks as well; the off-diagonal 90+ % of the flops are plain GEMM.
 // Geometry: 256 threads = 4 waves; wave w owns rows [16w,16w+16) of the 64-row block x 32 columns = 2 MFMA fragments.
-// LDS: up to 4 solved blocks X_e as MFMA B operands, [64][48] each (row stride 48 == 16 mod 32 -> conflict-free reads).
+// LDS: up to 3 solved blocks X_e as MFMA B operands (the 4th is staged in block 0's slot), [64][48] each (row stride 48 == 16 mod 32
+// -> conflict-free reads).
 // =====================================================================================================================
 constexpr int TF_MAXN = 256;
 constexpr int TF_COLS = 32;
@@ -102,7 +103,12 @@ __global__ void __launch_bounds__(256) trsm_fused_kernel(int n, int64_t nrhs, co
                                                          const T* __restrict__ Linv, T* __restrict__ B, int64_t ldb)
 {
     typedef typename MfmaT<T>::acc_t acc_t;
-    __shared__ T Xs[(TF_MAXN / NB) * NB * TF_XLD];
+    // Three slots for four blocks: the LAST block of a 256-row triangle is staged in block 0's slot -- by then nobody multiplies by
+    // X_0 any more.  72 KB instead of 96 KB (Float64): TWO workgroups per CU.  The update stream's block-row solves (496 workgroups
+    // on 224 CUs: 2.2 rounds of one workgroup per CU) were 82 us per launch, two launches per block column on the stream that sets
+    // the pace of the update-bound part (round 4; with 24 KB of LDS ballast, i.e. the old occupancy: N=16384 77.46-77.75 vs 77.28-77.48 ms).
+    constexpr int TF_SLOTS = TF_MAXN / NB - 1;
+    __shared__ T Xs[TF_SLOTS * NB * TF_XLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t col0 = (int64_t)blockIdx.x * TF_COLS;
     const int nblk = (n + NB - 1) / NB;
@@ -138,7 +144,8 @@ __global__ void __launch_bounds__(256) trsm_fused_kernel(int n, int64_t nrhs, co
             }
         }
         // ---- stage acc as a B operand, then X_d = inv(L_dd) * acc ----
-        T* Xd = Xs + d * NB * TF_XLD;
+        if (d >= TF_SLOTS) __syncthreads();   // every wave is done with X_0 before its slot is reused (workgroup-uniform)
+        T* Xd = Xs + (d < TF_SLOTS ? d : 0) * NB * TF_XLD;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll

@@ -51,6 +51,9 @@ struct TrsmRowG {
 // sL, sX: NB*NB elements of LDS each.  All 256 threads of the workgroup must call this.
 // UPPER: the block is the NON-unit UPPER triangle U of the same storage and the result is inv(U): U' = L'*D with the unit lower
 // L'[i][j] = U[j][i] / U[j][j], so inv(U)[i][j] = inv(L')[j][i] / U[j][j] -- the same machinery on the scaled transpose.
+// LDS images: element (i, j) at i*NB + ((j + i) & 63) (columns of row i rotated by i) -- with the plain row-major image every access
+// that walks down a column puts all its lanes on one bank pair (round 4: see diag_inv_block16 below).
+#define RFLU_INV4_IDX(i, j) ((i) * NB + ((((j) + (i))) & (NB - 1)))
 template <typename T, bool UPPER = false>
 __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lblk, int64_t ldl, T* __restrict__ Linv,
                                                 T* sL, T* sX, int tid)
@@ -64,8 +67,8 @@ __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lb
             const int j = c0 + e;
             T v = T(0);
             if (i < nb && j < i) v = UPPER ? Lblk[(int64_t)j * ldl + i] / Lblk[(int64_t)j * ldl + j] : Lblk[(int64_t)i * ldl + j];
-            sL[i * NB + j] = v;
-            sX[i * NB + j] = T(0);
+            sL[RFLU_INV4_IDX(i, j)] = v;
+            sX[RFLU_INV4_IDX(i, j)] = T(0);
         }
     }
     __syncthreads();
@@ -73,13 +76,21 @@ __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lb
     {
         const int wave = tid >> 6, lane = tid & 63;
         if (wave < 2 && lane < H) {
-            const T* blk = sL + (wave * H) * NB + wave * H;
+            const int o = wave * H;
             T x[H];
 #pragma unroll
             for (int i = 0; i < H; ++i) x[i] = (i == lane) ? T(1) : T(0);
-            TrsmRowG<T, 1, H>::run(blk, NB, x);
 #pragma unroll
-            for (int i = 0; i < H; ++i) sX[(wave * H + i) * NB + wave * H + lane] = x[i];
+            for (int i = 1; i < H; ++i) {
+                T acc[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+                for (int k = 0; k < i; ++k) acc[k & 3] += sL[RFLU_INV4_IDX(o + i, o + k)] * x[k];
+                T sv = x[i] - ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+                asm volatile("" : "+v"(sv) : : "memory");   // see TrsmRow
+                x[i] = sv;
+            }
+#pragma unroll
+            for (int i = 0; i < H; ++i) sX[RFLU_INV4_IDX(o + i, o + lane)] = x[i];
         }
     }
     __syncthreads();
@@ -89,13 +100,13 @@ __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lb
         T t[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll 8
         for (int k = 0; k < H; ++k) {
-            const T b = sL[(H + i) * NB + k];
+            const T bv = sL[RFLU_INV4_IDX(H + i, k)];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] += b * sX[k * NB + j0 + e];
+            for (int e = 0; e < 4; ++e) t[e] += bv * sX[RFLU_INV4_IDX(k, j0 + e)];
         }
         __syncthreads();   // everybody has read B before the quadrant next to it is overwritten (different quadrant: cheap safety)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sL[i * NB + H + j0 + e] = t[e];
+        for (int e = 0; e < 4; ++e) sL[RFLU_INV4_IDX(i, H + j0 + e)] = t[e];
     }
     __syncthreads();
     // lower left block of the inverse: -inv(C) * T
@@ -104,12 +115,12 @@ __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lb
         T t[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll 8
         for (int k = 0; k < H; ++k) {
-            const T c = sX[(H + i) * NB + H + k];
+            const T c = sX[RFLU_INV4_IDX(H + i, H + k)];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] += c * sL[k * NB + H + j0 + e];
+            for (int e = 0; e < 4; ++e) t[e] += c * sL[RFLU_INV4_IDX(k, H + j0 + e)];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sX[(H + i) * NB + j0 + e] = -t[e];
+        for (int e = 0; e < 4; ++e) sX[RFLU_INV4_IDX(H + i, j0 + e)] = -t[e];
     }
     __syncthreads();
     {
@@ -117,12 +128,12 @@ __device__ __forceinline__ void diag_inv_block4(int nb, const T* __restrict__ Lb
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int j = c0 + e;
-            if (UPPER) Linv[i * NB + j] = sX[j * NB + i] / (j < nb ? Lblk[(int64_t)j * ldl + j] : T(1));
-            else Linv[i * NB + j] = sX[i * NB + j];
+            if (UPPER) Linv[i * NB + j] = sX[RFLU_INV4_IDX(j, i)] / (j < nb ? Lblk[(int64_t)j * ldl + j] : T(1));
+            else Linv[i * NB + j] = sX[RFLU_INV4_IDX(i, j)];
         }
     }
 }
-
+#undef RFLU_INV4_IDX
 
 // ---- round 4: the same inverse with three levels of blocking and the products on the matrix cores --------------------------------
 // The interchange launch behind every leaf ends when its inverting workgroup does, and that workgroup was the long pole: 10 us

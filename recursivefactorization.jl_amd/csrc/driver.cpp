@@ -88,6 +88,7 @@ void Tune::load_env()
     env_flag("RFLU_TIME_ENQUEUE", time_enqueue);
     env_get("RFLU_SWAP_LATE", swap_late);
     env_get("RFLU_SWAP_ROWS", swap_rows);
+    env_get("RFLU_LEAF_FUSE", leaf_fuse);
     env_get("RFLU_TAIL_OVERLAP", tail_overlap);
     env_get("RFLU_HOST_EARLY_OUT", host_early_out);
     env_flag("RFLU_HOST_TRACE", host_trace);
@@ -944,7 +945,20 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);
             const unsigned long long* wflag = nullptr;   // leaf g-1 reached LA through the side stream: in its own block's part, or the next block's
             if (la1 > la0 && g > gfirst) wflag = h->gate_ptr[la0 < std::min(((c0 - NB) / W + 1) * W, n) ? 1 : 2];
-            if (f.pivot && fold) {   // both gates ride on the interchange launch: two launches less per leaf on this stream
+            // one launch for {interchanges on LA, diagonal inverse, 64-row solve of LA}: full leaves with a full, 16-byte aligned LA
+            const bool fuse = f.pivot && fold && h->tune.leaf_fuse && w == NB && la1 - la0 == NB && m - c0 > NB &&
+                              reinterpret_cast<uintptr_t>(R) % 16 == 0 && ld % (16 / (int64_t)sizeof(T)) == 0;
+            if (fuse) {
+                LaswpGate gt;
+                gt.wait_flag = wflag;
+                gt.wait_val = wflag ? val(g - 1) : 0;
+                gt.signal_flag = h->gate_ptr[0];
+                gt.signal_val = val(g);
+                gt.signal_cnt = reinterpret_cast<unsigned*>(h->gates + 4);
+                gt.info = h->info_dev;
+                RFLU_TRY(launch_leaf_la<T>(h, R, ld, la0, c0 / NB, c0, R + c0 * ld + c0, f.linv_at(c0), gt));
+                RFLU_TRY(launch_gemm<T>(h, m - c0 - w, la1 - la0, w, R + (c0 + w) * ld + c0, ld, R + c0 * ld + la0, ld, R + (c0 + w) * ld + la0, ld));
+            } else if (f.pivot && fold) {   // both gates ride on the interchange launch: two launches less per leaf on this stream
                 LaswpGate gt;
                 gt.wait_flag = wflag;
                 gt.wait_val = wflag ? val(g - 1) : 0;
@@ -959,7 +973,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
 
                 RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g), stamp(0, g)));
             }
-            RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
+            if (!fuse) RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
             // ---- side stream: leaf g on the rest of this block column and on the next one ----
             h->stream = S;
             int rc = launch_gate_wait(h, h->gate_ptr[0], val(g));

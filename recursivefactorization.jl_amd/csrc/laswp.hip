@@ -184,6 +184,155 @@ int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64
     return launch_laswp3<T>(h, R, ld, c0, ncolsA, c1, ncolsB, 0, 0, chunk0, chunk1, inv_nb, 1, inv_L, inv_out, gate);
 }
 
+
+// ---- leaf-wise schedule: everything the critical path does to the NEXT leaf's 64 columns behind a leaf, short of the K = 64 update,
+// in ONE launch of ONE workgroup (round 4).  Before: {interchanges on those columns || inverse of the leaf's diagonal block} (10.7 us,
+// the inverse the long pole), then a launch of its own for X = inv(L11) * B_top (6.3 us, most of it the round trip of the inverse
+// through memory).  Here the workgroup reads the leaf's move list and ALL moved rows of the 64 columns into registers (the loads
+// travel while the block is inverted), stores the displaced rows, keeps the 64 rows that end up on top in LDS, multiplies them by
+// the inverse it has just built (same v_mfma sequence as trsm_inv64_kernel: bit-identical) and stores X.  The inverse still goes
+// to memory for the side stream's solves.
+#define RFLU_LA_IDX(i, j) ((i) * NB + ((((j) + (i))) & (NB - 1)))
+template <typename T>
+__global__ void __launch_bounds__(256) leaf_la_kernel(T* __restrict__ R, int64_t ld, int64_t la0, const int* __restrict__ pm_cnt,
+                                                      const int* __restrict__ pm_dst, const int* __restrict__ pm_src, int chunk,
+                                                      int c0, const T* inv_L, T* inv_out, LaswpGate gate)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char la_smem[];
+    __shared__ int s_src[2 * NB], s_dst[2 * NB], s_top[NB], s_cnt;
+    T* sL = reinterpret_cast<T*>(la_smem);
+    T* sX = sL + NB * NB;
+    T* sB = sX + NB * NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the leaf's diagonal block and its move list are final since the leaf kernel ended: requested before the gate (which is about
+    // the side stream's writes to LA) so that their latency, the gate's and each other's run side by side
+    T lv[16];
+    diag_inv_load16<T>(NB, inv_L, ld, tid, lv);
+    int my_src = 0, my_dst = 0, my_cnt = 0;
+    if (tid < 2 * NB) {
+        my_src = pm_src[(size_t)chunk * 2 * NB + tid];
+        my_dst = pm_dst[(size_t)chunk * 2 * NB + tid];
+    }
+    if (tid == 0) my_cnt = pm_cnt[chunk];
+    if (gate.wait_flag) {   // folded stream gate, as in laswp_kernel
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(gate.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gate.wait_val) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > 200000000LL) {
+                    __hip_atomic_fetch_or((unsigned long long*)(gate.info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the move list: row s_src[k] -> row s_dst[k], k < cnt <= 128; which row ends up at top position p
+    if (tid < 2 * NB) {
+        s_src[tid] = my_src;
+        s_dst[tid] = my_dst;
+    }
+    if (tid == 0) s_cnt = my_cnt;
+    if (tid < NB) s_top[tid] = c0 + tid;
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (tid < cnt) {
+        const int d = s_dst[tid];
+        if (d >= c0 && d < c0 + NB) s_top[d - c0] = s_src[tid];   // destinations are distinct
+    }
+    __syncthreads();
+    // ---- every row this launch will overwrite is read first: the moved rows (two threads per move, 32 columns each) and the top
+    // rows that stay where they are (four threads per row, 16 columns each)
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    const int k = tid >> 1, hf = tid & 1;
+    const bool mv = k < cnt;
+    vec_t rv[32 / VW];
+    if (mv) {
+        const T* sp = R + (int64_t)s_src[k] * ld + la0 + hf * 32;
+#pragma unroll
+        for (int v = 0; v < 32 / VW; ++v) rv[v] = *reinterpret_cast<const vec_t*>(sp + v * VW);
+    }
+    const int p = tid >> 2, q = tid & 3;
+    const bool stay = s_top[p] == c0 + p;
+    vec_t tv[16 / VW];
+    if (stay) {
+        const T* sp = R + (int64_t)(c0 + p) * ld + la0 + q * 16;
+#pragma unroll
+        for (int v = 0; v < 16 / VW; ++v) tv[v] = *reinterpret_cast<const vec_t*>(sp + v * VW);
+    }
+    // ---- the inverse of the leaf's diagonal block (-> sX, rotated image, and inv_out) while those rows travel
+    diag_inv_block16_pre<T>(lv, inv_out, sL, sX, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every row has been read by whoever needs it: now they may be overwritten
+    if (mv) {
+        const int d = s_dst[k];
+        if (d >= c0 + NB) {
+            T* dp = R + (int64_t)d * ld + la0 + hf * 32;
+#pragma unroll
+            for (int v = 0; v < 32 / VW; ++v) *reinterpret_cast<vec_t*>(dp + v * VW) = rv[v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < 32 / VW; ++v)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) sB[RFLU_LA_IDX(d - c0, hf * 32 + v * VW + e)] = rv[v][e];
+        }
+    }
+    if (stay) {
+#pragma unroll
+        for (int v = 0; v < 16 / VW; ++v)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) sB[RFLU_LA_IDX(p, q * 16 + v * VW + e)] = tv[v][e];
+    }
+    __syncthreads();
+    // ---- X = inv(L11) * B_top: wave w -> rows 16w .. 16w+15, four column tiles (the operand order of trsm_inv64_kernel)
+    {
+        typedef typename InvMfma<T>::acc_t acc_t;
+        const int fi = lane & 15, fk = lane >> 4;
+        acc_t x[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const T a = sX[RFLU_LA_IDX(wave * 16 + fi, kk * 4 + fk)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = InvMfma<T>::run(a, sB[RFLU_LA_IDX(kk * 4 + fk, t * 16 + fi)], x[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                R[(int64_t)(c0 + wave * 16 + InvMfma<T>::crow(lane, r)) * ld + la0 + t * 16 + fi] = x[t][r];
+    }
+    if (gate.signal_flag) {
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            if (atomicInc(gate.signal_cnt, gridDim.x - 1) == gridDim.x - 1)
+                __hip_atomic_store(gate.signal_flag, gate.signal_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+#undef RFLU_LA_IDX
+
+template <typename T>
+int launch_leaf_la(Handle* h, T* R, int64_t ld, int64_t la0, int64_t chunk, int64_t c0, const T* inv_L, T* inv_out, LaswpGate gate)
+{
+    const size_t lds = 3 * (size_t)NB * NB * sizeof(T);
+    bool& attr_set = h->la_attr_set[sizeof(T) == 8 ? 0 : 1];
+    if (!attr_set) {
+        RFLU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&leaf_la_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    ProfScope ps(h, RFLU_K_LASWP, 4.0 * sizeof(T) * (double)NB * (double)NB);
+    hipLaunchKernelGGL(leaf_la_kernel<T>, dim3(1), dim3(256), lds, h->stream, R, ld, la0, h->pm_cnt, h->pm_dst, h->pm_src, (int)chunk, (int)c0,
+                       inv_L, inv_out, gate);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+template int launch_leaf_la<double>(Handle*, double*, int64_t, int64_t, int64_t, int64_t, const double*, double*, LaswpGate);
+template int launch_leaf_la<float>(Handle*, float*, int64_t, int64_t, int64_t, int64_t, const float*, float*, LaswpGate);
+
 template <typename T>
 int launch_laswp(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncols, int64_t chunk0, int64_t chunk1)
 {

@@ -99,6 +99,7 @@ struct Tune {
     int host_trace = 0;                // RFLU_HOST_TRACE
     int swap_late = 1;                 // RFLU_SWAP_LATE: leaf-wise schedule: side stream on the 224-CU stream (updates on the 192-CU one) from the first panel of at most swap_rows rows on, also behind a lookahead part (0: round 3's assignment)
     int64_t swap_rows = 8192;          // RFLU_SWAP_ROWS
+    int leaf_fuse = 1;                 // RFLU_LEAF_FUSE: leaf-wise schedule: interchanges + diagonal inverse + 64-row solve of the next leaf's columns in ONE launch (leaf_la_kernel)
     int host_threads = 8;              // RFLU_HOST_THREADS
     // multi-GPU
     int64_t mgpu_big_reserve = 128;    // RFLU_MGPU_BIG_RESERVE
@@ -189,6 +190,7 @@ struct Handle {
     int trsv_max_wgs = 0;        // same for the cooperative solve kernels (asked on first use)
     int panel_max_wgs = 0;       // how many workgroups of the cooperative panel kernels the device holds at once (occupancy query)
     bool coop_launch = false;    // RFLU_COOP_LAUNCH=1: hipLaunchCooperativeKernel (launch-time residency check, +15-19 us each)
+    bool la_attr_set[2] = {false, false};     // dynamic-LDS opt-in of leaf_la_kernel (f64, f32)
     bool gemm_attr_set[2] = {false, false};   // dynamic-LDS opt-in of the GEMM kernels done on this handle's device (f64, f32)
     int64_t* info_pinned = nullptr;
 
@@ -299,6 +301,10 @@ template <typename T>
 int launch_laswp2(Handle* h, T* R, int64_t ld, int64_t c0, int64_t ncolsA, int64_t c1, int64_t ncolsB, int64_t chunk0,
                   int64_t chunk1, int64_t inv_nb = 0, const T* inv_L = nullptr, T* inv_out = nullptr,
                   LaswpGate gate = LaswpGate{});
+// leaf-wise schedule, one launch behind a full leaf (rows / columns c0.., move list `chunk`): the leaf's interchanges on the next
+// leaf's 64 columns [la0, la0 + 64), the inverse of its diagonal block (-> inv_out) and the solve of those columns' top 64 rows
+template <typename T>
+int launch_leaf_la(Handle* h, T* R, int64_t ld, int64_t la0, int64_t chunk, int64_t c0, const T* inv_L, T* inv_out, LaswpGate gate);
 // fold the interchanges ipiv[k0..k1) (k0 a multiple of NB) into per-chunk row-move lists
 int launch_perm_build(Handle* h, const int64_t* ipiv, int64_t k0, int64_t k1, int64_t m);
 size_t panel_scratch_bytes();

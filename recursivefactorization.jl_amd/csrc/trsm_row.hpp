@@ -180,17 +180,32 @@ __device__ __forceinline__ void inv_tile_prod(const T* MA, int ar, int ac, const
 }
 
 // sL, sX: NB*NB elements of LDS each.  All 256 threads of the workgroup must call this.
+// the block's strictly lower part, 16 entries of row tid >> 2 per thread (zero elsewhere, also outside nb: the padding inverts to the
+// identity): a caller that has other memory latencies to wait for requests it first and hands it to diag_inv_block16_pre
+template <typename T>
+__device__ __forceinline__ void diag_inv_load16(int nb, const T* __restrict__ Lblk, int64_t ldl, int tid, T (&v)[16])
+{
+    const int i = tid >> 2, c0 = (tid & 3) * 16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = (i < nb && c0 + e < i) ? Lblk[(int64_t)i * ldl + c0 + e] : T(0);
+}
+template <typename T>
+__device__ __forceinline__ void diag_inv_block16_pre(const T (&v)[16], T* __restrict__ Linv, T* sL, T* sX, int tid);
 template <typename T>
 __device__ __forceinline__ void diag_inv_block16(int nb, const T* __restrict__ Lblk, int64_t ldl, T* __restrict__ Linv, T* sL, T* sX,
                                                  int tid)
 {
+    T v[16];
+    diag_inv_load16<T>(nb, Lblk, ldl, tid, v);
+    diag_inv_block16_pre<T>(v, Linv, sL, sX, tid);
+}
+template <typename T>
+__device__ __forceinline__ void diag_inv_block16_pre(const T (&v)[16], T* __restrict__ Linv, T* sL, T* sX, int tid)
+{
     constexpr int Q = NB / 4, H = NB / 2;
     const int wave = tid >> 6, lane = tid & 63;
-    {   // strictly lower part of the block into sL (zero elsewhere, also outside nb: the padding inverts to the identity)
+    {
         const int i = tid >> 2, c0 = (tid & 3) * 16;
-        T v[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = (i < nb && c0 + e < i) ? Lblk[(int64_t)i * ldl + c0 + e] : T(0);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             sL[RFLU_INV_IDX(i, c0 + e)] = v[e];

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: everything the documents quote, from ONE box: size table, default bench line, microbenches, rocprofv3 summaries.
 # usage (on the GPU box): bash scripts/r04_final.sh <tag>      then, here: python scripts/install_profiles.py <tag>
-TAG=${1:-r04h}
+TAG=${1:-r04i}
 cd "$(dirname "$0")/.."
 O=gpurun_out/r04; mkdir -p $O
 rm -f $O/bench_n*.json

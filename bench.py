@@ -400,6 +400,17 @@ def main():
         lw = {k: lw_small[k] + lw_wide[k] for k in ("ms", "launches", "work")}
         if roof is not None and g2["launches"] > 0 and g2["ms"] > 0:
             ach2 = g2["work"] / (g2["ms"] * 1e-3) / 1e12
+            # the top-level achieved / frac are the SHIPPED schedule's figure; the single-stream profiled pass is kept beside it
+            roof["achieved_profiled"] = roof["achieved"]
+            roof["frac_profiled"] = roof["frac"]
+            roof["avg_launch_ms_profiled"] = roof["avg_launch_ms"]
+            roof["launches_profiled"] = roof["launches"]
+            roof["achieved"] = round(ach2, 3)
+            roof["frac"] = round(ach2 / PEAK_TFLOPS[sfx], 4)
+            roof["avg_launch_ms"] = round(g2["ms"] / g2["launches"], 4)
+            roof["launches"] = g2["launches"]
+            roof["flops_per_launch"] = g2["work"] / g2["launches"]
+            roof["algorithmic_bytes_per_launch"] = g2["bytes"] / g2["launches"]
             roof["achieved_in_schedule"] = round(ach2, 3)
             roof["frac_in_schedule"] = round(ach2 / PEAK_TFLOPS[sfx], 4)
             roof["launches_in_schedule"] = g2["launches"]
@@ -655,7 +666,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             # N > 1 lines are read against one_gpu_same_n (the same n on one GPU in the same run): strong scaling, the form the
             # north star's ">= 6x at 8 GPUs over 1 GPU on N=65536" is stated in; the N = 1 line is the headline configuration
-            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": sfx, "data": "synthetic",
+            "scaling": "n/a" if world == 1 else "strong", "vs_baseline": None, "dtype": sfx, "data": "synthetic",
             "config": {"workload": f"lu!(A, ipiv) of a dense uniform[0,1) {n}x{n} {'Float64' if sfx == 'f64' else 'Float32'} "
                                    f"matrix, {'partial pivoting' if pivot else 'NoPivot'}, column-major in HBM",
                        "n": n, "pivot": bool(pivot), "blocksize": args.blocksize,

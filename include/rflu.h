@@ -203,6 +203,10 @@ int rflu_mgpu_is_fake(rflu_mgpu_t mgpu);
  * RFLU_MGPU_FORCE_RCCL=1 made a one-device object build a one-rank communicator and broadcast to itself: the way the
  * collective's code path is executed on a box with a single GPU) */
 int64_t rflu_mgpu_collectives(rflu_mgpu_t mgpu);
+/* The RFLU_* tuning variables are read ONCE per handle (rflu_create / rflu_mgpu_create).  A host that changes them between
+ * calls asks for another read: rflu_reload_tuning for a single-GPU handle, this one for the per-device handles of a multi-GPU
+ * object. */
+int rflu_mgpu_reload_tuning(rflu_mgpu_t mgpu);
 /* number of local columns of logical device d for an n-column matrix (-1 on bad arguments) */
 int64_t rflu_mgpu_local_cols(int64_t n, int64_t block, int ndev, int64_t run, int d);
 int rflu_getrf_f64_mgpu(rflu_mgpu_t mgpu, int64_t n, double* const* slabs_dev, const int64_t* lds, int64_t* ipiv_host,

@@ -53,6 +53,7 @@ _PLAIN = {
     "rflu_debug_heat": (c_int, [c_p, ctypes.c_double]),
     "rflu_debug_gate_stamps": (c_int, [c_p, c_p]),
     "rflu_mgpu_create": (c_int, [ctypes.POINTER(c_p), c_int, ctypes.POINTER(c_int)]),
+    "rflu_mgpu_reload_tuning": (c_int, [c_p]),
     "rflu_mgpu_destroy": (c_int, [c_p]),
     "rflu_mgpu_ndev": (c_int, [c_p]),
     "rflu_mgpu_is_fake": (c_int, [c_p]),
@@ -178,7 +179,24 @@ def default_handle(device: int = 0) -> Handle:
     return _handles[device]
 
 
+_mgpu_objects: "weakref.WeakSet" = None  # live MultiGPU objects (multigpu.py registers itself)
+
+
+def register_mgpu(obj) -> None:
+    global _mgpu_objects
+    import weakref
+
+    if _mgpu_objects is None:
+        _mgpu_objects = weakref.WeakSet()
+    _mgpu_objects.add(obj)
+
+
 def reload_tuning() -> None:
-    """Every default handle reads the RFLU_* environment variables again (after a host changed them between calls)."""
+    """The RFLU_* variables are read ONCE per handle, at creation; changing os.environ later is ignored until this is called.
+    Every default handle and every live MultiGPU object's per-device handles read the environment again.  (A Handle built
+    by the caller has its own ``reload_tuning()``.)"""
     for h in _handles.values():
         h.reload_tuning()
+    for g in list(_mgpu_objects or ()):
+        if getattr(g, "ptr", None) is not None and g.ptr.value:
+            check(g.lib.rflu_mgpu_reload_tuning(g.ptr))

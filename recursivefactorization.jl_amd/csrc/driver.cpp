@@ -51,6 +51,7 @@ void Tune::load_env()
     env_get("RFLU_PANEL_PW", panel_pw);
     env_get("RFLU_PANEL_MAXG", panel_maxg);
     env_get("RFLU_PANEL_RPW", panel_rpw);
+    if (panel_rpw != 64 && panel_rpw != 128 && panel_rpw != 256 && panel_rpw != 384 && panel_rpw != 512) panel_rpw = 0;   // the kernels that exist
     env_get("RFLU_PANEL_SPARE", panel_spare);
     env_get("RFLU_PANEL_SPARE_MIN", panel_spare_min);
     env_get("RFLU_PANEL_BALLAST", panel_ballast);
@@ -85,6 +86,9 @@ void Tune::load_env()
     env_get("RFLU_GATE_FOLD", gate_fold);
     env_flag("RFLU_GATE_TRACE", gate_trace);
     if (const char* e = env_str("RFLU_SCHEDULE")) schedule_events = strcmp(e, "events") == 0;
+    // rocprofv3 --pmc exports this into the profiled process and runs one kernel at a time: a device-side gate would only ever
+    // see its timeout, so a counter-collection run takes the event schedule by itself (RFLU_SCHEDULE=gates overrides)
+    else if (env_str("ROCPROF_COUNTER_COLLECTION")) schedule_events = 1;
     env_flag("RFLU_TIME_ENQUEUE", time_enqueue);
     env_get("RFLU_SWAP_LATE", swap_late);
     env_get("RFLU_SWAP_ROWS", swap_rows);
@@ -528,10 +532,12 @@ static int validate_queues(Handle* h)
         if (verbose) fprintf(stderr, "[rflu] queue check: placement not settled after %d checks, %zu streams parked: no further checks on this handle\n",
                              h->queue_unresolved, h->parked_streams.size());
     }
-    if (h->queues_ok_streams.size() >= 8) h->queues_ok_streams.erase(h->queues_ok_streams.begin());
     bool known = false;
     for (hipStream_t ok : h->queues_ok_streams) known = known || ok == P;
-    if (!known) h->queues_ok_streams.push_back(P);
+    if (!known) {
+        if (h->queues_ok_streams.size() >= 8) h->queues_ok_streams.erase(h->queues_ok_streams.begin());
+        h->queues_ok_streams.push_back(P);
+    }
     h->queues_ok_count = 0;
     for (int r = 1; r < 8; ++r) h->queues_ok_count += (h->ustreams[r] != nullptr) + (h->pstreams[r] != nullptr);
     return RFLU_OK;
@@ -686,7 +692,9 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
         int reserve = std::max<int>(min_reserve, int((std::max<int64_t>(g_next, 1) + 31) / 32 * 32));
         // RFLU_SWAP_LATE (default on): the last block column in front of a leaf-wise part that starts swapped sends its update to the
         // 192-CU stream, so that the 224-CU stream is free to be the side stream of the first leaf-wise block column (factor_leafwise)
-        if (h->tune.swap_late && reserve == 32 && last_here && b_end < nid && rows_next <= h->tune.swap_rows) reserve = 64;
+        // (RFLU_SWAP_SU overrides factor_leafwise's stream assignment: only its "swapped behind a lookahead part" mode wants this move)
+        const bool swapped_at_handover = h->tune.swap_su >= 0 ? h->tune.swap_su == 2 : h->tune.swap_late != 0;
+        if (swapped_at_handover && reserve == 32 && last_here && b_end < nid && rows_next <= h->tune.swap_rows) reserve = 64;
         if (reserve > std::min(max_reserve, 224)) {
             // the next panel needs (almost) the whole GPU: run this block column on one stream
             if (uend_prev >= 0) {
@@ -2270,6 +2278,13 @@ int rflu_mgpu_destroy(rflu_mgpu_t m)
 int rflu_mgpu_ndev(rflu_mgpu_t m) { return m ? MG(m)->ndev : 0; }
 int rflu_mgpu_is_fake(rflu_mgpu_t m) { return m ? (MG(m)->fake ? 1 : 0) : 0; }
 int64_t rflu_mgpu_collectives(rflu_mgpu_t m) { return m ? MG(m)->ncoll : 0; }
+
+int rflu_mgpu_reload_tuning(rflu_mgpu_t m)
+{
+    if (!m) { set_error("null multi-GPU object"); return RFLU_ERR_ARG; }
+    for (Handle* h : MG(m)->h) load_handle_env(h);   // the per-device handles read RFLU_* again, like rflu_reload_tuning
+    return RFLU_OK;
+}
 
 int64_t rflu_mgpu_local_cols(int64_t n, int64_t block, int ndev, int64_t run, int d)
 {

@@ -24,6 +24,7 @@ class MultiGPU:
         arr = (ctypes.c_int * self.ndev)(*self.devs)
         _ffi.check(self.lib.rflu_mgpu_create(ctypes.byref(self.ptr), self.ndev, arr))
         self.fake = bool(self.lib.rflu_mgpu_is_fake(self.ptr))
+        _ffi.register_mgpu(self)   # _ffi.reload_tuning() reaches the per-device handles too
 
     @property
     def collectives(self) -> int:

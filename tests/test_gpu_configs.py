@@ -32,6 +32,54 @@ def _free(*ts):
     torch.cuda.empty_cache()
 
 
+def _cpu_pivots_of_left_panel(n, k, seed=12):
+    """The first k pivots of a factorization depend on the first k columns only: `ipiv` of the CPU path (the threaded oracle,
+    src/lu.jl:298-305 restated) and of LAPACK dgetrf on the tall n x k left panel of the SAME matrix -- the generator's counter
+    is j*m + i, so `fill_uniform(n, k, seed)` is exactly the first k columns of `fill_uniform(n, n, seed)`."""
+    import os
+    import oracle as O
+    O.use_native()
+    O.set_threads(min(64, os.cpu_count() or 1))
+    try:
+        A = O.fill_uniform(n, k, seed)
+        _, ipo, info_o = O.lu(A)
+    finally:
+        O.set_threads(1)
+    assert info_o == 0
+    piv_lapack = None
+    try:
+        import scipy.linalg as sla
+        _, piv, info_l = sla.lapack.dgetrf(A, overwrite_a=True)
+        assert info_l == 0
+        piv_lapack = piv.astype(np.int64) + 1
+    except ImportError:
+        pass
+    return ipo, piv_lapack
+
+
+def _assert_leading_pivots_equal_cpu_path(dA, ip_gpu, n, k=4096):
+    ipo, piv_lapack = _cpu_pivots_of_left_panel(n, k)
+    # same input on both sides: a strided sample of the device matrix's left panel against the host generator
+    idx = torch.arange(0, n, 1021, device=dA.device)
+    jdx = torch.arange(0, k, 127, device=dA.device)
+    assert np.array_equal(dA[idx][:, jdx].cpu().numpy(), _sample_uniform(n, 12, np.arange(0, n, 1021), np.arange(0, k, 127)))
+    ip = ip_gpu[:k].cpu().numpy()
+    assert np.array_equal(ip, ipo), f"first difference from the CPU path at pivot {int(np.argmax(ip != ipo))}"
+    if piv_lapack is not None:
+        assert np.array_equal(ip, piv_lapack), f"first difference from dgetrf at pivot {int(np.argmax(ip != piv_lapack))}"
+
+
+def _sample_uniform(m, seed, rows, cols):
+    """entries (rows x cols) of the m x m generator matrix without building it (oracle.np_uniform's arithmetic)"""
+    with np.errstate(over="ignore"):
+        ctr = cols.astype(np.uint64)[None, :] * np.uint64(m) + rows.astype(np.uint64)[:, None]
+        z = np.uint64(seed) + (ctr + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
 @pytest.mark.parametrize("blocksize", [64, 128, 256, 0])
 def test_config2_n16384_block_size_sweep(blocksize, record_property):
     n = 16384
@@ -65,6 +113,8 @@ def test_config3_n32768(record_property):
     record_property("residual", res)
     assert res < 1e-12, res
     ip = F.ipiv.clone()
+    # the first 4096 pivots against the CPU path (threaded oracle and dgetrf on the tall left panel): the 64-workgroup leaves
+    _assert_leading_pivots_equal_cpu_path(A, ip, n)
     _free(A, F)
     _, G = _factor(n, np.float64, True, 512)   # the multi-GPU layout's block width
     assert torch.equal(ip, G.ipiv)
@@ -78,6 +128,9 @@ def test_config4_n65536_float64(record_property):
     record_property("residual", res)
     assert res < 1e-12, res
     ip = F.ipiv.clone()
+    # the first 4096 pivots against the CPU path: 128-workgroup leaves and the single-stream branch for panels of more than
+    # 32768 rows (src/lu.jl:298-305 on 65536 rows; ~1.1 TFLOP of host work)
+    _assert_leading_pivots_equal_cpu_path(A, ip, n)
     _free(A, F)
     _, G = _factor(n, np.float64, True, 1024)
     assert torch.equal(ip, G.ipiv)
@@ -168,7 +221,7 @@ def test_headline_n16384_ipiv_equals_cpu_path(record_property):
 def test_headline_size_float32_info_and_residual_vs_cpu_path(record_property):
     """N=16384 Float32 against the CPU path: `info` equal and both residuals inside the reference's bound E = 20 n eps
     (test/runtests.jl:19-20).  Float32 pivot sequences may fork between two equally valid summation orders from n ~ 1500 on
-    (DESIGN.md section 5), so the number of equal leading pivots is reported, not asserted."""
+    (DESIGN.md section 5), so the number of equal leading pivots is reported and only a floor (1024) is asserted."""
     import os
     import oracle as O
     n = 16384
@@ -193,6 +246,9 @@ def test_headline_size_float32_info_and_residual_vs_cpu_path(record_property):
     print(f"N=16384 Float32: residual GPU {res:.3e}, CPU path {res_cpu:.3e}, equal leading pivots {same} of {n}")
     assert res < E and res_cpu < E, (res, res_cpu)
     assert res < 4 * res_cpu + 1e-6
+    # forks are legitimate from n ~ 1500 on (two candidates closer than the rounding error of two summation orders), but a broken
+    # Float32 search would fork at once: the leading pivots have to agree
+    assert same >= 1024, same
     _free(dA, F, dFo)
 
 

@@ -9,9 +9,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "librflu.so")
-SOURCES = ["gemm.hip", "panel.hip", "panel_f32.hip", "panel_local.hip", "panel_local_f32.hip", "panel_local_xcd.hip", "panel_local_xcd_f32.hip", "panel_single.hip", "panel_single_f32.hip", "panel_blocked.hip", "panel_blocked_f32.hip", "trsm.hip", "trsv.hip", "laswp.hip", "butterfly.hip", "driver.cpp"]
-HEADERS = ["rflu_internal.hpp", "panel_common.hpp", "panel_xchg.hpp", "trsm_row.hpp", os.path.join("..", "..", "include", "rflu.h")]
-EXTRA_DEPS = {"panel_f32.hip": ["panel.hip"], "panel_local_f32.hip": ["panel_local.hip"], "panel_local_xcd.hip": ["panel_local.hip"], "panel_local_xcd_f32.hip": ["panel_local.hip"], "panel_single_f32.hip": ["panel_single.hip"], "panel_blocked_f32.hip": ["panel_blocked.hip"]}  # a source that #includes another source
+SOURCES = ["gemm.hip", "engine.hip", "panel.hip", "panel_f32.hip", "panel_local.hip", "panel_local_f32.hip", "panel_local_xcd.hip", "panel_local_xcd_f32.hip", "panel_single.hip", "panel_single_f32.hip", "panel_blocked.hip", "panel_blocked_f32.hip", "trsm.hip", "trsv.hip", "laswp.hip", "butterfly.hip", "driver.cpp"]
+HEADERS = ["rflu_internal.hpp", os.path.join("..", "..", "include", "rflu.h")]   # included by every source
+ALL_HEADERS = HEADERS + ["panel_common.hpp", "panel_xchg.hpp", "trsm_row.hpp", "gemm_tile.hpp", "laswp_strip.hpp", "engine.hpp"]
+_PANEL_H = ["panel_common.hpp", "panel_xchg.hpp", "trsm_row.hpp"]
+EXTRA_DEPS = {"gemm.hip": ["gemm_tile.hpp"], "engine.hip": ["gemm_tile.hpp", "laswp_strip.hpp", "engine.hpp"], "driver.cpp": ["engine.hpp"],
+              "laswp.hip": ["laswp_strip.hpp", "trsm_row.hpp"], "trsm.hip": ["trsm_row.hpp"], "trsv.hip": ["trsm_row.hpp"],
+              "panel.hip": _PANEL_H, "panel_local.hip": _PANEL_H, "panel_single.hip": _PANEL_H, "panel_blocked.hip": _PANEL_H,
+              "panel_f32.hip": ["panel.hip", *_PANEL_H], "panel_local_f32.hip": ["panel_local.hip", *_PANEL_H],
+              "panel_local_xcd.hip": ["panel_local.hip", *_PANEL_H], "panel_local_xcd_f32.hip": ["panel_local.hip", *_PANEL_H],
+              "panel_single_f32.hip": ["panel_single.hip", *_PANEL_H], "panel_blocked_f32.hip": ["panel_blocked.hip", *_PANEL_H]}
+# (a source that #includes another source, or a header only some sources see: kept per source so that touching one
+#  kernel family does not rebuild the others)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
 
 
@@ -32,7 +41,7 @@ def _digest(paths):
 
 def sources_digest() -> str:
     """One hash over every kernel / driver source and header: identifies the build a measurement belongs to."""
-    return _digest([os.path.join(CSRC, f) for f in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS])
+    return _digest([os.path.join(CSRC, f) for f in SOURCES] + [os.path.join(CSRC, h) for h in ALL_HEADERS])
 
 
 def _hipcc():

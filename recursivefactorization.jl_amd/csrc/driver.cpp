@@ -21,6 +21,7 @@
 #include <new>
 
 #include "rflu_internal.hpp"
+#include "engine.hpp"
 #include <chrono>
 #include <thread>
 
@@ -101,6 +102,15 @@ void Tune::load_env()
     env_get("RFLU_MGPU_TALL_ROWS", mgpu_tall_rows);
     env_get("RFLU_MGPU_SYNC", mgpu_sync);
     env_get("RFLU_DEBUG_GHOST_LEAF", debug_ghost_leaf);
+    env_get("RFLU_ENGINE", engine);
+    env_get("RFLU_ENGINE_POLICY", engine_policy);
+    env_get("RFLU_ENGINE_WGS", engine_wgs);
+    env_get("RFLU_ENGINE_NOPANEL", engine_nopanel);
+    for (int i = 0; i < 8; ++i) {
+        char name[32];
+        snprintf(name, sizeof(name), "RFLU_ENGINE_X%d", i);
+        env_get(name, engine_x[i]);
+    }
 }
 
 // the handle's own switches (kernel routing) + its Tune
@@ -815,6 +825,100 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     return RFLU_OK;
 }
 
+// Block-column schedule with the persistent update engine (engine.hip): the critical-path stream does nothing but the panels --
+//   P : [wait ready[b]] Toledo recursion on block column b (interchanges confined to its own columns) -> panel_done = b + 1
+// -- and every trailing update (interchanges, block-row solve, Schur update, the deferred interchanges to the left) is pulled by
+// the engine's resident workgroups from per-column-block counters, on the CUs of the 224-CU mask.  Same eliminations in the same
+// order on every column as factor_lookahead; the block-row solve walks its 64-row blocks left-looking instead of by recursive
+// halving, so factors agree to rounding and pivots exactly (tests/test_gpu_engine.py).
+// b_end < number of block columns: panels [0, b_end) only; block column b_end is up to date when this returns (on P), the rest
+// of the engine's work is ordered in front of *E_out by evUend(b_end - 1) / the stream itself (factor_leafwise goes on from there).
+template <typename T>
+static int engine_usable(const Handle* h, const Fact<T>& f, int64_t W)
+{
+    constexpr int64_t VW = 16 / (int64_t)sizeof(T);
+    return h->tune.engine != 0 && W % 128 == 0 && f.roff == 0 && reinterpret_cast<uintptr_t>(f.R) % 16 == 0 && f.ld % VW == 0 &&
+           f.m < (int64_t)1 << 30 && f.n < (int64_t)1 << 30 && (f.n + W - 1) / W <= ENG_MAX_CB && !h->progress && !h->mask_failed &&
+           !h->tune.schedule_events &&
+           (f.m >= f.n || f.m % W == 0);   // (a fat matrix whose last panel ends inside a column block: the columns right of it in that block)
+}
+
+template <typename T>
+static int factor_engine(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* E_out)
+{
+    Handle* h = f.h;
+    const int64_t m = f.m, n = f.n, mn = std::min(m, n);
+    const int64_t nblk = (mn + W - 1) / W, ncb = (n + W - 1) / W;
+    int64_t nbp = std::min(b_end, nblk);
+    if (h->tune.engine_nopanel && h->tune.engine_x[2] > 0) nbp = std::min<int64_t>(nbp, h->tune.engine_x[2]);   // measurement: the first panels only
+    hipStream_t P = h->stream, E;
+    RFLU_TRY(get_ustream(h, 32, &E));
+    if (!h->eng_state) {
+        RFLU_HIP(hipMalloc(&h->eng_state, sizeof(EngState)));
+        RFLU_HIP(hipHostMalloc(&h->eng_host, sizeof(EngState), hipHostMallocDefault));
+    }
+    EngState* st = static_cast<EngState*>(h->eng_state);
+    EngState* img = static_cast<EngState*>(h->eng_host);
+    const size_t bytes = offsetof(EngState, cb) + (size_t)ncb * sizeof(EngCB);
+    memset(img, 0, bytes);
+    for (int64_t cb = 0; cb < ncb; ++cb) {
+        EngCB& c = img->cb[cb];
+        const int64_t upd = std::min(cb, nbp);   // panels that update this column block
+        c.claim = upd > 0 ? 0ull : (unsigned long long)ENG_SEQ_DONE << 32;
+        c.ready = upd > 0 ? 0ull : 1ull;
+        img->remaining += upd > 0;
+        const bool left = f.pivot && cb + 1 < nbp;   // later panels' interchanges on this (by then finished) column block
+        c.lclaim = left ? (unsigned long long)(cb + 1) << 32 : (unsigned long long)ENG_SEQ_DONE << 32;
+        img->remaining += left;
+    }
+    // the initial state travels on the caller's stream: the first panel_done signal (same stream) can never overtake it
+    RFLU_HIP(hipMemcpyAsync(st, img, bytes, hipMemcpyHostToDevice, P));
+    hipEvent_t ev;
+    RFLU_TRY(get_event(h, 0, &ev));
+    RFLU_HIP(hipEventRecord(ev, P));               // ... and whatever produced the matrix there
+    RFLU_HIP(hipStreamWaitEvent(E, ev, 0));
+    EngArgs<T> a;
+    a.R = f.R; a.ld = f.ld; a.m = (int)m; a.n = (int)n; a.mn = (int)mn; a.W = (int)W; a.nbp = (int)nbp; a.ncb = (int)ncb;
+    a.pivot = f.pivot; a.policy = h->tune.engine_policy;
+    a.linv = static_cast<const T*>(h->linv); a.pm_cnt = h->pm_cnt; a.pm_dst = h->pm_dst; a.pm_src = h->pm_src;
+    a.st = st; a.info = h->info_dev; a.gemm_flags = h->tune.gemm_flags;
+    for (int i = 0; i < 8; ++i) a.x[i] = h->tune.engine_x[i];
+    const int wgs = h->tune.engine_wgs > 0 ? h->tune.engine_wgs : 2 * (h->num_cus - 32);
+    if (img->remaining > 0) RFLU_TRY(launch_engine<T>(h, E, a, wgs));
+    h->eng_active = true;
+    // While the engine is resident the only CUs with room are the 4 per XCD its mask leaves out: the any-placement leaves (at most 32
+    // workgroups, one per CU) fit there, the XCD-local ones (all participants on ONE XCD) do not -- they would wait for CUs the
+    // engine never gives back
+    struct Restore { Fact<T>& f; int64_t local_rows; ~Restore() { f.sw_lo = 0; f.sw_hi = -1; f.h->tune.panel_local_rows = local_rows; } }
+        restore{f, h->tune.panel_local_rows};
+    h->tune.panel_local_rows = 0;
+    if (h->tune.engine_nopanel) {   // measurement only (wrong factors): every panel "done" at once -- what the engine does by itself
+        RFLU_TRY(launch_eng_signal(h, &st->panel_done, (unsigned long long)nbp));
+    }
+    for (int64_t b = 0; b < nbp && !h->tune.engine_nopanel; ++b) {
+        const int64_t j0 = b * W, je = std::min(j0 + W, mn);
+        if (b > 0) RFLU_TRY(launch_eng_wait(h, &st->cb[b].ready, 1));
+        f.sw_lo = j0;
+        f.sw_hi = je;
+        RFLU_TRY(f.rec(j0, je));
+        if (b == 0 && f.tail) {   // the engine's stream is the one the layout change's tail ran on; P's next panels read those columns
+            RFLU_HIP(hipStreamWaitEvent(P, f.tail, 0));
+            f.tail = nullptr;
+        }
+        RFLU_TRY(launch_eng_signal(h, &st->panel_done, (unsigned long long)b + 1, &st->cb[b].t_panel));
+    }
+    if (nbp < nblk) RFLU_TRY(launch_eng_wait(h, &st->cb[nbp].ready, 1));   // the next block column is somebody else's panel
+    // the engine leaves when every column block has received everything: evUend of the last block column = its end
+    RFLU_TRY(get_event(h, 4 * (size_t)std::max<int64_t>(nbp - 1, 0) + 3, &ev));
+    RFLU_HIP(hipEventRecord(ev, E));
+    if (E_out) *E_out = E;
+    if (nbp >= nblk) {
+        RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
+        h->eng_active = false;
+    }
+    return RFLU_OK;
+}
+
 // Leaf-wise schedule: the critical path is nothing but the chain of cooperative leaves.
 //
 // The recursion's merges (solve + Schur update of the right half) and the block-column lookahead put ~640 us of small
@@ -996,8 +1100,16 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                 h->stream = S;
                 if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g), stamp(1, g));
                 hipEvent_t e;
+                if (h->eng_active && b == b_begin) {
+                    // behind the update engine (factor_engine): the next block column is up to date when its ready word says so
+                    if (rc == RFLU_OK && b + 1 < (n + W - 1) / W) {
+                        h->stream = S;
+                        rc = launch_eng_wait(h, &static_cast<EngState*>(h->eng_state)->cb[b + 1].ready, 1);
+                    }
+                } else {
                 if (rc == RFLU_OK) rc = get_event(h, evU1(b - 1), &e);
                 if (rc == RFLU_OK && hipStreamWaitEvent(S, e, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); rc = RFLU_ERR_HIP; }
+                }
                 if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, std::max(la1, bend), wend, true);
                 h->stream = S;
                 if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[2], val(g), stamp(2, g));
@@ -1047,6 +1159,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         h->stream = userS;
     }
     RFLU_TRY(wait_on(userS, evUend(nblk - 1)));
+    h->eng_active = false;
     return RFLU_OK;
 }
 
@@ -1143,7 +1256,14 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
                 tail = nullptr;
             }
             f.tail = tail;
-            if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last, W_wide, wide_end));
+            if (b_switch > 0 && W_wide == 0 && engine_usable<T>(h, f, Wb)) {
+                if (tail) {   // the layout change's tail runs on the 224-CU stream: the engine is launched behind it on that stream
+                    hipStream_t E;
+                    RFLU_TRY(get_ustream(h, 32, &E));
+                    (void)E;
+                }
+                RFLU_TRY(factor_engine<T>(f, Wb, b_switch, &U_last));
+            } else if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last, W_wide, wide_end));
             if (b_switch < nblk) RFLU_TRY(factor_leafwise<T>(f, Wb, b_switch, U_last));
         }
         if (h->tune.time_enqueue)
@@ -1639,6 +1759,19 @@ int rflu_debug_gate_stamps(rflu_handle_t handle, long long* out)
     CHECK_HANDLE(handle);
     if (!H(handle)->gate_stamps) { set_error("no gate trace (set RFLU_GATE_TRACE=1)"); return RFLU_ERR_ARG; }
     RFLU_HIP(hipMemcpy(out, H(handle)->gate_stamps, 3 * 4096 * sizeof(long long), hipMemcpyDeviceToHost));
+    return RFLU_OK;
+}
+
+// measurement only (scripts/engine_trace.py): per block column of the last factorization that used the update engine, the wall clock
+// (100 MHz ticks) at which its column block had received every update (t_ready) and at which its panel was published (t_panel)
+int rflu_debug_engine_times(rflu_handle_t handle, long long* t_ready, long long* t_panel, int n)
+{
+    CHECK_HANDLE(handle);
+    Handle* h = H(handle);
+    if (!h->eng_state || n < 0 || n > ENG_MAX_CB) { set_error("no engine state (or n out of range)"); return RFLU_ERR_ARG; }
+    std::vector<EngCB> tmp((size_t)n);
+    RFLU_HIP(hipMemcpy(tmp.data(), static_cast<EngState*>(h->eng_state)->cb, (size_t)n * sizeof(EngCB), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { t_ready[i] = tmp[i].t_ready; t_panel[i] = tmp[i].t_panel; }
     return RFLU_OK;
 }
 

@@ -1,0 +1,465 @@
+// engine.hip -- the persistent update engine: every trailing update of the block-column schedule as ONE resident kernel that
+// pulls its work from device-side counters.
+//
+// What it replaces.  schur_complement! (/root/reference/src/lu.jl:265-284), the block-row ldiv! (:235) and apply_permutation!
+// (:164-188) of the trailing matrix were three launch sequences per block column on a CU-masked "update stream" (driver.cpp:
+// factor_lookahead): interchanges -> block-row solve -> one bulk GEMM whose workgroups take their tiles in a fixed order.  The
+// bulk GEMM reached 46-50 TFLOP/s there against 57.7 alone on the same CUs: every launch ramps up and tails off, the stream's
+// own interchanges / solves run with the matrix cores idle (7 % of its time), and a block column's update cannot start before the
+// previous one has drained although only the SAME columns depend on each other.
+//
+// Design.  The trailing matrix is a set of COLUMN BLOCKS (W columns).  Column block cb has to receive the updates of panels
+// b = 0 .. cb-1 in that order, each as two stages ("sequences", seq = 2b + stage):
+//     stage 0: the interchanges of panel b on its columns + X = inv(L11) * A12       (units of 32 columns, one workgroup each)
+//     stage 1: A22 -= A21 * X                                                        (units of one 128 x 128 tile)
+// and different column blocks are independent of each other.  Per column block a 64-bit claim word (seq << 32 | next unit) and a
+// done counter live in device memory; the 2 x (CUs of the mask) resident workgroups loop { scan the claim words (one lane per column
+// block) -> pick the eligible unit of highest priority -> fetch-and-add on its claim word -> agent-scope acquire -> run the unit ->
+// agent-scope release -> count it done; the last finisher of a sequence publishes the next one }.  A stage-0 sequence of panel b is
+// eligible once the critical-path stream has published panel_done > b; a column block that has received everything raises its
+// `ready` word, which the critical-path stream waits for in front of that block column's panel.  No workgroup ever waits for a
+// particular other workgroup: a unit is claimed only when everything it reads is final, so residency is a matter of speed, not of
+// correctness.  The interchanges that later panels owe the FINISHED column blocks to their left are units of lowest priority.
+// Inter-workgroup visibility follows MI355X_MICROARCH.md ("Workgroup dispatch ..."): producer = every wave drains its stores,
+// barrier, one lane's agent-scope release fence (buffer_wbl2 sc1) + s_waitcnt, then the counter; consumer = relaxed poll of the
+// claim word, one lane's agent-scope acquire (buffer_inv sc1), barrier, plain loads.
+//
+// Roofline: the stage-1 units are gemm_tile (gemm_tile.hpp), fp64 MFMA bound, 2 * 128 * 128 * W flops each.
+#include <limits.h>
+
+#include "engine.hpp"
+#include "gemm_tile.hpp"
+#include "laswp_strip.hpp"
+
+namespace rflu {
+
+constexpr int EP_COLS = 32;             // columns of a stage-0 unit
+constexpr int EP_XLD = EP_COLS + 16;    // LDS row pitch of the staged block (== 16 mod 32 doubles: conflict-free fragment reads)
+
+template <typename T>
+__device__ __forceinline__ int eng_units(const EngArgs<T>& a, int cb, unsigned seq)
+{
+    const int b = (int)(seq >> 1);
+    const int je = min(b * a.W + a.W, a.mn);
+    const int nc = min(a.W, a.n - cb * a.W);
+    if ((seq & 1u) == 0) return (nc + EP_COLS - 1) / EP_COLS;
+    const int rows = a.m - je;
+    if (rows <= 0) return 0;
+    return ((rows + G_BM - 1) / G_BM) * ((nc + G_BN - 1) / G_BN);
+}
+
+template <typename T>
+__device__ __forceinline__ int eng_left_units(const EngArgs<T>& a, int cb)
+{
+    constexpr int SC = 8 * (16 / (int)sizeof(T));
+    const int nc = min(a.W, a.n - cb * a.W);
+    return (nc + 4 * SC - 1) / (4 * SC);
+}
+
+__device__ __forceinline__ unsigned long long eng_load(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void eng_store(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void eng_release()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (MI355X_MICROARCH.md)
+}
+
+// ---- stage 0: interchanges of panel b on 32 columns of column block cb, then X = inv(L11) * A12 on those columns ----------------
+// The solve is trsm_fused_kernel's left-looking walk over 64-row blocks with pre-inverted diagonal blocks (trsm.hip), for a block
+// row of any height: the solved blocks X_e are read back from memory (this workgroup's own stores, drained + barrier) instead of
+// being kept in LDS, so W = 512 ... 2048 rows cost 24 KB of LDS.  Wave w owns rows [16w, 16w+16) of a 64-row block x 32 columns.
+template <typename T>
+__device__ __attribute__((noinline)) void eng_prep_unit(const EngArgs<T>& a, int cb, int b, int u, T* smem)
+{
+    typedef typename Mfma<T>::acc_t acc_t;
+    constexpr int VW = 16 / (int)sizeof(T);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = b * a.W, je = min(j0 + a.W, a.mn), jb = je - j0;
+    const int ncb_cols = min(a.W, a.n - cb * a.W);
+    const int c0 = cb * a.W + u * EP_COLS;
+    const int nc = min(EP_COLS, ncb_cols - u * EP_COLS);
+    T* const R = a.R;
+    const int64_t ld = a.ld;
+    if (a.pivot) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int chunk0 = j0 / NB, chunk1 = (je + NB - 1) / NB;
+        if (nc % VW == 0) {
+            constexpr int SC = 8 * VW;
+            if (wv < (nc + SC - 1) / SC)
+                laswp_strip<T, VW, 8>(R, ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, wv);
+        } else {
+            if (wv < (nc + 7) / 8)
+                laswp_strip<T, 1, 8>(R, ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, wv);
+        }
+        __syncthreads();   // (every chunk of laswp_strip ends with s_waitcnt vmcnt(0): the rows are in place)
+    }
+    const T* L = R + (int64_t)j0 * ld + j0;
+    const T* Linv = a.linv + (int64_t)(j0 / NB) * NB * NB;
+    T* B = R + (int64_t)j0 * ld + c0;
+    const int nblk = (jb + NB - 1) / NB;
+    const int fi = lane & 15, fk = lane >> 4;
+    const int arow = wave * 16 + fi;
+    T* Xd = smem;
+    for (int d = 0; d < nblk; ++d) {
+        const int rows_d = min(NB, jb - d * NB);
+        acc_t acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 16 + Mfma<T>::crow(lane, r);
+                const int col = t * 16 + fi;
+                acc[t][r] = (row < rows_d && col < nc) ? B[(int64_t)(d * NB + row) * ld + col] : T(0);
+            }
+        const bool rok = arow < rows_d;
+        for (int e = 0; e < d; ++e) {
+            T av[16], b0[16], b1[16];
+            const T* Lp = L + (int64_t)(d * NB + arow) * ld + e * NB + fk;
+            const T* Xe = B + (int64_t)(e * NB + fk) * ld + fi;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                av[kk] = rok ? -Lp[kk * 4] : T(0);
+                b0[kk] = fi < nc ? Xe[(int64_t)(kk * 4) * ld] : T(0);
+                b1[kk] = 16 + fi < nc ? Xe[(int64_t)(kk * 4) * ld + 16] : T(0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                acc[0] = Mfma<T>::run(av[kk], b0[kk], acc[0]);
+                acc[1] = Mfma<T>::run(av[kk], b1[kk], acc[1]);
+            }
+        }
+        // stage acc as a B operand, then X_d = inv(L_dd) * acc
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xd[(wave * 16 + Mfma<T>::crow(lane, r)) * EP_XLD + t * 16 + fi] = acc[t][r];
+        T ai[16];
+        {
+            const T* Ip = Linv + (int64_t)d * NB * NB + arow * NB + fk;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) ai[kk] = Ip[kk * 4];
+        }
+        __syncthreads();
+        acc_t x[2] = {acc_t{T(0), T(0), T(0), T(0)}, acc_t{T(0), T(0), T(0), T(0)}};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const T q0 = Xd[(kk * 4 + fk) * EP_XLD + fi];
+            const T q1 = Xd[(kk * 4 + fk) * EP_XLD + 16 + fi];
+            x[0] = Mfma<T>::run(ai[kk], q0, x[0]);
+            x[1] = Mfma<T>::run(ai[kk], q1, x[1]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 16 + Mfma<T>::crow(lane, r);
+                const int col = t * 16 + fi;
+                if (row < rows_d && col < nc) B[(int64_t)(d * NB + row) * ld + col] = x[t][r];
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X_d is in memory before any wave of this workgroup reads it back
+        __syncthreads();                                     // (and everybody has read the staged block)
+    }
+}
+
+// ---- stage 1: one 128 x 128 tile of A22 -= A21 * X --------------------------------------------------------------------------------
+template <typename T>
+__device__ __attribute__((noinline)) void eng_gemm_unit(const EngArgs<T>& a, int cb, int b, int t, T* smem)
+{
+    constexpr int VW = 16 / (int)sizeof(T);
+    const int j0 = b * a.W, je = min(j0 + a.W, a.mn);
+    const int cc = cb * a.W;
+    GemmArgs<T> g;
+    g.M = a.m - je;
+    g.N = min(a.W, a.n - cc);
+    g.K = je - j0;
+    g.A = a.R + (int64_t)je * a.ld + j0;
+    g.B = a.R + (int64_t)j0 * a.ld + cc;
+    g.C = a.R + (int64_t)je * a.ld + cc;
+    g.lda = g.ldb = g.ldc = a.ld;
+    g.tiles_m = (g.M + G_BM - 1) / G_BM;
+    g.tiles_n = (g.N + G_BN - 1) / G_BN;
+    g.vec_ok = (reinterpret_cast<uintptr_t>(a.R) % 16 == 0) && (a.ld % VW == 0);
+    g.flags = a.gemm_flags;
+    g.na_tiles_n = 0; g.sig_flag = nullptr; g.sig_val = 0; g.sig_cnt = nullptr;
+    // G_GROUP_M tile rows are walked together, column after column: consecutive claims share the B panel, then the A panels
+    const int per_group = G_GROUP_M * g.tiles_n;
+    const int group = t / per_group;
+    const int first_m = group * G_GROUP_M;
+    const int gsz = min(g.tiles_m - first_m, G_GROUP_M);
+    const int in_group = t - group * per_group;
+    const int tile_m = first_m + in_group % gsz;
+    const int tile_n = in_group / gsz;
+    const int m0 = tile_m * G_BM, n0 = tile_n * G_BN;
+    const bool full_mn = g.vec_ok && (m0 + G_BM <= g.M) && (n0 + G_BN <= g.N);
+    if (full_mn && (g.K % G_BK) == 0 && g.K >= 2 * G_BK) gemm_tile<T, true, true>(g, smem, m0, n0);
+    else gemm_tile<T, true, false>(g, smem, m0, n0);
+}
+
+// ---- deferred interchanges of panel b on the finished column block cb (to the left of the panel): 4 wave strips per unit ----------
+template <typename T>
+__device__ __attribute__((noinline)) void eng_left_unit(const EngArgs<T>& a, int cb, int b, int u)
+{
+    constexpr int VW = 16 / (int)sizeof(T);
+    constexpr int SC = 8 * VW;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j0 = b * a.W, je = min(j0 + a.W, a.mn);
+    const int ncb_cols = min(a.W, a.n - cb * a.W);
+    const int c0 = cb * a.W + u * 4 * SC;
+    const int nc = min(4 * SC, ncb_cols - u * 4 * SC);
+    const int chunk0 = j0 / NB, chunk1 = (je + NB - 1) / NB;
+    if (nc % VW == 0) {
+        if (wave < (nc + SC - 1) / SC)
+            laswp_strip<T, VW, 8>(a.R, a.ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, wave);
+    } else {
+        for (int s = wave; s < (nc + 7) / 8; s += 4)
+            laswp_strip<T, 1, 8>(a.R, a.ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, s);
+    }
+}
+
+enum { ENG_NONE = 0, ENG_MAIN = 1, ENG_LEFT = 2, ENG_EXIT = 3 };
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char eng_smem_raw[];
+    T* smem = reinterpret_cast<T*>(eng_smem_raw);
+    __shared__ int s_sel[4];   // kind, column block, sequence, unit
+    EngState* const st = a.st;
+    const int tid = threadIdx.x, lane = tid & 63;
+    long long idle_since = -1;
+    int idle_rounds = 0;
+
+    for (;;) {
+        if (tid < 64) {
+            int kind = ENG_NONE, sel_cb = 0, sel_unit = 0;
+            unsigned sel_seq = 0;
+            for (int attempt = 0; attempt < 4 && kind == ENG_NONE; ++attempt) {
+                if (eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0) { kind = ENG_EXIT; break; }
+                const unsigned long long pd = eng_load(&st->panel_done);
+                // ---- main units: one lane per column block -----------------------------------------------------------------
+                int best = INT_MAX;
+                for (int base = 0; base < a.ncb; base += 64) {
+                    const int cb = base + lane;
+                    int key = INT_MAX;
+                    unsigned long long w = 0;
+                    if (cb < a.ncb) {
+                        w = eng_load(&st->cb[cb].claim);
+                        const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
+                        if (seq != ENG_SEQ_DONE) {
+                            const int b = (int)(seq >> 1);
+                            if ((unsigned long long)b < pd && (int)u < eng_units(a, cb, seq)) key = a.policy ? cb : ((b << 10) | cb);
+                        }
+                    }
+                    int mk = key;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
+                    best = min(best, mk);
+                }
+                if (best != INT_MAX) {
+                    // fetch-and-add, not compare-and-swap: with a few hundred workgroups arriving together a CAS hands out ONE unit per
+                    // round trip (the losers rescan: 384 tiles took 0.6 ms to hand out).  Whatever (sequence, unit) the add returns is
+                    // this workgroup's if the unit exists; a count past the end is nobody's (the next sequence starts from zero again).
+                    const int cb = best & 1023;
+                    unsigned long long w = 0;
+                    if (lane == 0) w = __hip_atomic_fetch_add(&st->cb[cb].claim, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w = __shfl(w, 0);
+                    const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
+                    if (seq != ENG_SEQ_DONE && (int)u < eng_units(a, cb, seq)) {
+                        kind = ENG_MAIN; sel_cb = cb; sel_seq = seq; sel_unit = (int)u;
+                        // The scan saw an eligible sequence; the add may have landed in a LATER one (published in between).  A later
+                        // stage 1 is ready by construction; a later stage 0 needs its panel -- practically never the case (a whole
+                        // sequence would have to complete between this wave's scan and its add), but then the claim is held until
+                        // the panel is there (bounded; the panel does not depend on this workgroup)
+                        if ((seq & 1u) == 0) {
+                            const long long t0 = wall_clock64();
+                            while (eng_load(&st->panel_done) <= (unsigned long long)(seq >> 1) && eng_load(&st->abort) == 0) {
+                                __builtin_amdgcn_s_sleep(16);
+                                if (wall_clock64() - t0 > 400000000LL) break;   // (the idle timeout of the others raises the flag)
+                            }
+                        }
+                    }
+                    continue;   // (past the end: look again)
+                }
+                // ---- deferred interchanges to the left of the panels ------------------------------------------------------
+                if (a.pivot) {
+                    int bestl = INT_MAX;
+                    for (int base = 0; base < a.ncb; base += 64) {
+                        const int cb = base + lane;
+                        int key = INT_MAX;
+                        unsigned long long w = 0;
+                        if (cb < a.ncb) {
+                            w = eng_load(&st->cb[cb].lclaim);
+                            const unsigned b = (unsigned)(w >> 32), u = (unsigned)w;
+                            if (b != ENG_SEQ_DONE && (unsigned long long)b < pd && (int)u < eng_left_units(a, cb)) key = ((int)b << 10) | cb;
+                        }
+                        int mk = key;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
+                        bestl = min(bestl, mk);
+                    }
+                    if (bestl != INT_MAX) {
+                        const int cb = bestl & 1023;
+                        unsigned long long w = 0;
+                        if (lane == 0) w = __hip_atomic_fetch_add(&st->cb[cb].lclaim, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w = __shfl(w, 0);
+                        const unsigned b = (unsigned)(w >> 32), u = (unsigned)w;
+                        if (b != ENG_SEQ_DONE && (int)u < eng_left_units(a, cb)) {
+                            kind = ENG_LEFT; sel_cb = cb; sel_seq = b; sel_unit = (int)u;
+                            const long long t0 = wall_clock64();
+                            while (eng_load(&st->panel_done) <= (unsigned long long)b && eng_load(&st->abort) == 0) {
+                                __builtin_amdgcn_s_sleep(16);
+                                if (wall_clock64() - t0 > 400000000LL) break;
+                            }
+                        }
+                        continue;
+                    }
+                }
+                break;   // nothing is eligible right now
+            }
+            if (lane == 0) {
+                if ((kind == ENG_MAIN || kind == ENG_LEFT) && !(a.x[1] & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                s_sel[0] = kind; s_sel[1] = sel_cb; s_sel[2] = (int)sel_seq; s_sel[3] = sel_unit;
+            }
+        }
+        __syncthreads();
+        const int kind = s_sel[0], cb = s_sel[1], unit = s_sel[3];
+        const unsigned seq = (unsigned)s_sel[2];
+        if (kind == ENG_EXIT) break;
+        if (kind == ENG_NONE) {
+            // back off: a few hundred idle workgroups polling flat out would take memory bandwidth from the working ones
+            const long long now = wall_clock64();
+            if (idle_since < 0) idle_since = now;
+            if (now - idle_since > 400000000LL) {   // 4 s without any work: something upstream is stuck
+                if (tid == 0) {
+                    __hip_atomic_fetch_or((unsigned long long*)(a.info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    eng_store(&st->abort, 1ull);
+                }
+                break;
+            }
+            idle_rounds = min(idle_rounds + 1, 16);
+            for (int i = 0; i < idle_rounds; ++i) __builtin_amdgcn_s_sleep(32);
+            __syncthreads();   // s_sel is rewritten by wave 0 in the next round
+            continue;
+        }
+        idle_since = -1;
+        idle_rounds = 0;
+        if (kind == ENG_MAIN) {
+            const int b = (int)(seq >> 1);
+            if ((seq & 1u) == 0) eng_prep_unit<T>(a, cb, b, unit, smem);
+            else eng_gemm_unit<T>(a, cb, b, unit, smem);
+        } else {
+            eng_left_unit<T>(a, cb, (int)seq, unit);
+        }
+        // ---- completion: drain every wave's stores, one lane releases and counts ------------------------------------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (!(a.x[0] & 1)) eng_release();
+            EngCB* c = &st->cb[cb];
+            if (kind == ENG_MAIN) {
+                const int units = eng_units(a, cb, seq);
+                const unsigned long long d = __hip_atomic_fetch_add(&c->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                if ((int)d == units) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                    eng_store(&c->done, 0ull);
+                    const unsigned end = 2u * (unsigned)min(cb, a.nbp);
+                    unsigned ns = seq + 1;
+                    while (ns < end && eng_units(a, cb, ns) == 0) ++ns;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (ns >= end) {
+                        c->t_ready = wall_clock64();
+                        __hip_atomic_store(&c->ready, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&c->claim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        __hip_atomic_store(&c->claim, (unsigned long long)ns << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            } else {
+                const int units = eng_left_units(a, cb);
+                const unsigned long long d = __hip_atomic_fetch_add(&c->ldone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                if ((int)d == units) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                    eng_store(&c->ldone, 0ull);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned nb = seq + 1;
+                    if ((int)nb >= a.nbp) {
+                        __hip_atomic_store(&c->lclaim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        __hip_atomic_store(&c->lclaim, (unsigned long long)nb << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+size_t engine_lds_bytes(size_t esize)
+{
+    return std::max<size_t>(2 * (size_t)G_STAGE * esize, (size_t)NB * EP_XLD * esize);
+}
+
+template <typename T>
+int launch_engine(Handle* h, hipStream_t stream, const EngArgs<T>& a, int wgs)
+{
+    const size_t lds = engine_lds_bytes(sizeof(T));
+    bool& attr_set = h->eng_attr_set[sizeof(T) == 8 ? 0 : 1];
+    if (!attr_set) {
+        RFLU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&engine_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((engine_kernel<T>), dim3((unsigned)wgs), dim3(256), lds, stream, a);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+template int launch_engine<double>(Handle*, hipStream_t, const EngArgs<double>&, int);
+template int launch_engine<float>(Handle*, hipStream_t, const EngArgs<float>&, int);
+
+// ---- the critical-path stream's side of the protocol ---------------------------------------------------------------------------------
+__global__ void eng_signal_kernel(unsigned long long* flag, unsigned long long value, long long* stamp)
+{
+    // (the kernels in front of this one on the stream have completed: their data is in memory)
+    if (stamp) *stamp = wall_clock64();
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void eng_wait_kernel(const unsigned long long* flag, unsigned long long value, unsigned long long* abort, int64_t* info)
+{
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+        if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // somebody has already given up
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > 400000000LL) {   // 4 s: the engine is stuck (or gone): raise the timeout flag, release everybody
+            __hip_atomic_fetch_or((unsigned long long*)(info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+int launch_eng_signal(Handle* h, unsigned long long* flag, unsigned long long value, long long* stamp)
+{
+    hipLaunchKernelGGL(eng_signal_kernel, dim3(1), dim3(1), 0, h->stream, flag, value, stamp);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+int launch_eng_wait(Handle* h, const unsigned long long* flag, unsigned long long value)
+{
+    EngState* st = static_cast<EngState*>(h->eng_state);
+    hipLaunchKernelGGL(eng_wait_kernel, dim3(1), dim3(1), 0, h->stream, flag, value, &st->abort, h->info_dev);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+}  // namespace rflu

@@ -108,6 +108,12 @@ struct Tune {
     // fault injection (tests): the cooperative leaf launch with this sequence number inside a factorization waits for a
     // participant that does not exist, runs into its bounded spin and raises the timeout flag (RFLU_ERR_TIMEOUT at the end)
     int debug_ghost_leaf = -1;         // RFLU_DEBUG_GHOST_LEAF
+    // persistent update engine (engine.hip)
+    int engine = 1;                    // RFLU_ENGINE: 1 = the trailing updates of the block-column schedule run in the persistent engine
+    int engine_policy = 0;             // RFLU_ENGINE_POLICY: 0 = oldest panel first, 1 = leftmost column block first
+    int engine_wgs = 0;                // RFLU_ENGINE_WGS: resident workgroups (0: two per CU of the update mask)
+    int engine_x[8] = {};              // RFLU_ENGINE_X0..7: experiment switches of the engine (meaning in engine.hip / driver.cpp; 0 = default)
+    int engine_nopanel = 0;            // RFLU_ENGINE_NOPANEL=1: measurement only (wrong factors): no panels, every update eligible at once
     void load_env();                   // driver.cpp
 };
 
@@ -192,6 +198,10 @@ struct Handle {
     bool coop_launch = false;    // RFLU_COOP_LAUNCH=1: hipLaunchCooperativeKernel (launch-time residency check, +15-19 us each)
     bool la_attr_set[2] = {false, false};     // dynamic-LDS opt-in of leaf_la_kernel (f64, f32)
     bool gemm_attr_set[2] = {false, false};   // dynamic-LDS opt-in of the GEMM kernels done on this handle's device (f64, f32)
+    bool eng_attr_set[2] = {false, false};    // same for the persistent update engine (engine.hip)
+    void* eng_state = nullptr;                // device: EngState (engine.hpp)
+    void* eng_host = nullptr;                 // pinned host image of its initial value
+    bool eng_active = false;                  // a factorization's engine is resident (factor_engine .. the join with its stream)
     int64_t* info_pinned = nullptr;
 
     // timers

@@ -1,0 +1,89 @@
+"""The persistent update engine (csrc/engine.hip) against the stream schedule it replaces, on one GPU: pivots equal, factors equal
+to rounding, residual, and the time of both.  usage: python scripts/engine_check.py [quick|time|all]"""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+from recursivefactorization.jl_amd import _ffi
+from gpu_util import fill_uniform_cm, matvec_residual
+
+h = _ffi.Handle(0); h.set_stream(None)
+mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+
+
+def factor(n, sfx, bs, env, reps=1, m=None, pivot=1):
+    for k in list(os.environ):
+        if k.startswith("RFLU_"):
+            del os.environ[k]
+    os.environ.update(env)
+    h.reload_tuning()
+    dt = np.float64 if sfx == "f64" else np.float32
+    m = n if m is None else m
+    A0 = fill_uniform_cm(n, dt, 12, 10.0 if not pivot else 0.0, m=m)
+    best = 1e30
+    for _ in range(reps):
+        A = A0.clone()
+        ip = torch.zeros(min(m, n), dtype=torch.int64, device="cuda")
+        info = ctypes.c_int64(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h.call(f"rflu_getrf_{sfx}_dev", m, n, ctypes.c_void_p(A.data_ptr()), m, ctypes.c_void_p(ip.data_ptr()) if pivot else None, pivot, bs, ctypes.byref(info))
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return A0, A, ip, info.value, best * 1e3
+
+
+def compare(n, sfx, bs, env_extra=None, m=None, pivot=1):
+    e0 = {"RFLU_ENGINE": "0", **(env_extra or {})}
+    e1 = {"RFLU_ENGINE": "1", **(env_extra or {})}
+    A0, F0, ip0, i0, t0 = factor(n, sfx, bs, e0, m=m, pivot=pivot)
+    _, F1, ip1, i1, t1 = factor(n, sfx, bs, e1, m=m, pivot=pivot)
+    path = h.last_path()
+    same_piv = bool(torch.equal(ip0, ip1))
+    scale = float(F0.abs().max())
+    dmax = float((F0 - F1).abs().max()) / scale
+    res = matvec_residual(A0, F1, ip1 if pivot else np.arange(1, min(n, m or n) + 1)) if (m is None or m == n) else float("nan")
+    ok = same_piv and i0 == i1 and dmax < (1e-10 if sfx == "f64" else 1e-3)
+    print(f"{'OK ' if ok else 'BAD'} {sfx} m={m or n} n={n} bs={bs} piv={pivot} {env_extra or ''}: path {path} info {i0}/{i1} ipiv equal {same_piv} "
+          f"max|dF|/max|F| {dmax:.2e} residual {res:.2e}  [{t0:.2f} ms -> {t1:.2f} ms]", flush=True)
+    return ok
+
+
+if mode in ("quick", "all"):
+    allok = True
+    lw0 = {"RFLU_LEAFWISE": "0"}
+    for n, bs in [(1024, 256), (2048, 512), (3000, 256), (4096, 512), (2048, 128), (5000, 512), (8192, 512)]:
+        allok &= compare(n, "f64", bs, lw0)
+    allok &= compare(4096, "f32", 512, lw0)
+    allok &= compare(3000, "f32", 256, lw0)
+    allok &= compare(4096, "f64", 512, lw0, pivot=0)
+    allok &= compare(3072, "f64", 512, lw0, m=5000)            # tall
+    allok &= compare(5120, "f64", 512, lw0, m=3072)            # fat, m a multiple of W
+    allok &= compare(12288, "f64", 0)                          # engine part + leaf-wise part behind it
+    allok &= compare(4096, "f64", 512, {"RFLU_LEAFWISE": "0", "RFLU_ENGINE_POLICY": "1"})
+    print("ALL OK" if allok else "FAILURES", flush=True)
+
+if mode in ("time", "all"):
+    for n in (8192, 12288, 16384):
+        for env in ({"RFLU_ENGINE": "0"}, {"RFLU_ENGINE": "1"}, {"RFLU_ENGINE": "1", "RFLU_ENGINE_POLICY": "1"},
+                    {"RFLU_ENGINE": "0", "RFLU_LEAFWISE": "0"}, {"RFLU_ENGINE": "1", "RFLU_LEAFWISE": "0"},
+                    {"RFLU_ENGINE": "1", "RFLU_LEAFWISE": "0", "RFLU_ENGINE_POLICY": "1"}):
+            _, _, _, info, t = factor(n, "f64", 0, env, reps=4)
+            print(f"n={n} {env}: info {info} best {t:.2f} ms", flush=True)
+
+if mode in ("trace", "all"):
+    # per block column: when its panel could start (column block ready), when the panel was done, and the update latency behind it
+    for n, env in ((16384, {"RFLU_ENGINE": "1"}), (16384, {"RFLU_ENGINE": "1", "RFLU_ENGINE_POLICY": "1"}), (16384, {"RFLU_ENGINE": "1", "RFLU_LEAFWISE": "0"})):
+        _, _, _, info, t = factor(n, "f64", 0, env, reps=2)
+        nb = n // 512
+        tr = (ctypes.c_longlong * nb)(); tp = (ctypes.c_longlong * nb)()
+        h.call("rflu_debug_engine_times", tr, tp, nb)
+        t0 = tp[0]
+        print(f"n={n} {env}: {t:.2f} ms; per block column [us since panel 0 done]: ready, panel done, panel time, update latency")
+        for b in range(nb):
+            if tp[b] == 0:
+                break
+            rdy = (tr[b] - t0) / 100.0 if b > 0 else float('nan')
+            nxt = (tr[b + 1] - tp[b]) / 100.0 if b + 1 < nb and tr[b + 1] else float('nan')
+            print(f"  b={b:2d} ready {rdy:9.1f} panel_done {(tp[b] - t0) / 100.0:9.1f} panel {(tp[b] - tr[b]) / 100.0 if b else float('nan'):8.1f} next_ready_after {nxt:8.1f}", flush=True)

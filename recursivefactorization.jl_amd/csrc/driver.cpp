@@ -825,98 +825,16 @@ static int factor_lookahead(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* U
     return RFLU_OK;
 }
 
-// Block-column schedule with the persistent update engine (engine.hip): the critical-path stream does nothing but the panels --
-//   P : [wait ready[b]] Toledo recursion on block column b (interchanges confined to its own columns) -> panel_done = b + 1
-// -- and every trailing update (interchanges, block-row solve, Schur update, the deferred interchanges to the left) is pulled by
-// the engine's resident workgroups from per-column-block counters, on the CUs of the 224-CU mask.  Same eliminations in the same
-// order on every column as factor_lookahead; the block-row solve walks its 64-row blocks left-looking instead of by recursive
-// halving, so factors agree to rounding and pivots exactly (tests/test_gpu_engine.py).
-// b_end < number of block columns: panels [0, b_end) only; block column b_end is up to date when this returns (on P), the rest
-// of the engine's work is ordered in front of *E_out by evUend(b_end - 1) / the stream itself (factor_leafwise goes on from there).
+// The persistent update engine (engine.hip) can serve a factorization when the column blocks start on tile boundaries, the
+// workspace allows 16-byte accesses and nothing else wants to follow the schedule from the host (the host entry's progress hook).
 template <typename T>
 static int engine_usable(const Handle* h, const Fact<T>& f, int64_t W)
 {
     constexpr int64_t VW = 16 / (int64_t)sizeof(T);
     return h->tune.engine != 0 && W % 128 == 0 && f.roff == 0 && reinterpret_cast<uintptr_t>(f.R) % 16 == 0 && f.ld % VW == 0 &&
            f.m < (int64_t)1 << 30 && f.n < (int64_t)1 << 30 && (f.n + W - 1) / W <= ENG_MAX_CB && !h->progress && !h->mask_failed &&
-           !h->tune.schedule_events &&
+           !h->tune.schedule_events && h->num_cus == 256 &&
            (f.m >= f.n || f.m % W == 0);   // (a fat matrix whose last panel ends inside a column block: the columns right of it in that block)
-}
-
-template <typename T>
-static int factor_engine(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* E_out)
-{
-    Handle* h = f.h;
-    const int64_t m = f.m, n = f.n, mn = std::min(m, n);
-    const int64_t nblk = (mn + W - 1) / W, ncb = (n + W - 1) / W;
-    int64_t nbp = std::min(b_end, nblk);
-    if (h->tune.engine_nopanel && h->tune.engine_x[2] > 0) nbp = std::min<int64_t>(nbp, h->tune.engine_x[2]);   // measurement: the first panels only
-    hipStream_t P = h->stream, E;
-    RFLU_TRY(get_ustream(h, 32, &E));
-    if (!h->eng_state) {
-        RFLU_HIP(hipMalloc(&h->eng_state, sizeof(EngState)));
-        RFLU_HIP(hipHostMalloc(&h->eng_host, sizeof(EngState), hipHostMallocDefault));
-    }
-    EngState* st = static_cast<EngState*>(h->eng_state);
-    EngState* img = static_cast<EngState*>(h->eng_host);
-    const size_t bytes = offsetof(EngState, cb) + (size_t)ncb * sizeof(EngCB);
-    memset(img, 0, bytes);
-    for (int64_t cb = 0; cb < ncb; ++cb) {
-        EngCB& c = img->cb[cb];
-        const int64_t upd = std::min(cb, nbp);   // panels that update this column block
-        c.claim = upd > 0 ? 0ull : (unsigned long long)ENG_SEQ_DONE << 32;
-        c.ready = upd > 0 ? 0ull : 1ull;
-        img->remaining += upd > 0;
-        const bool left = f.pivot && cb + 1 < nbp;   // later panels' interchanges on this (by then finished) column block
-        c.lclaim = left ? (unsigned long long)(cb + 1) << 32 : (unsigned long long)ENG_SEQ_DONE << 32;
-        img->remaining += left;
-    }
-    // the initial state travels on the caller's stream: the first panel_done signal (same stream) can never overtake it
-    RFLU_HIP(hipMemcpyAsync(st, img, bytes, hipMemcpyHostToDevice, P));
-    hipEvent_t ev;
-    RFLU_TRY(get_event(h, 0, &ev));
-    RFLU_HIP(hipEventRecord(ev, P));               // ... and whatever produced the matrix there
-    RFLU_HIP(hipStreamWaitEvent(E, ev, 0));
-    EngArgs<T> a;
-    a.R = f.R; a.ld = f.ld; a.m = (int)m; a.n = (int)n; a.mn = (int)mn; a.W = (int)W; a.nbp = (int)nbp; a.ncb = (int)ncb;
-    a.pivot = f.pivot; a.policy = h->tune.engine_policy;
-    a.linv = static_cast<const T*>(h->linv); a.pm_cnt = h->pm_cnt; a.pm_dst = h->pm_dst; a.pm_src = h->pm_src;
-    a.st = st; a.info = h->info_dev; a.gemm_flags = h->tune.gemm_flags;
-    for (int i = 0; i < 8; ++i) a.x[i] = h->tune.engine_x[i];
-    const int wgs = h->tune.engine_wgs > 0 ? h->tune.engine_wgs : 2 * (h->num_cus - 32);
-    if (img->remaining > 0) RFLU_TRY(launch_engine<T>(h, E, a, wgs));
-    h->eng_active = true;
-    // While the engine is resident the only CUs with room are the 4 per XCD its mask leaves out: the any-placement leaves (at most 32
-    // workgroups, one per CU) fit there, the XCD-local ones (all participants on ONE XCD) do not -- they would wait for CUs the
-    // engine never gives back
-    struct Restore { Fact<T>& f; int64_t local_rows; ~Restore() { f.sw_lo = 0; f.sw_hi = -1; f.h->tune.panel_local_rows = local_rows; } }
-        restore{f, h->tune.panel_local_rows};
-    h->tune.panel_local_rows = 0;
-    if (h->tune.engine_nopanel) {   // measurement only (wrong factors): every panel "done" at once -- what the engine does by itself
-        RFLU_TRY(launch_eng_signal(h, &st->panel_done, (unsigned long long)nbp));
-    }
-    for (int64_t b = 0; b < nbp && !h->tune.engine_nopanel; ++b) {
-        const int64_t j0 = b * W, je = std::min(j0 + W, mn);
-        if (b > 0) RFLU_TRY(launch_eng_wait(h, &st->cb[b].ready, 1));
-        f.sw_lo = j0;
-        f.sw_hi = je;
-        RFLU_TRY(f.rec(j0, je));
-        if (b == 0 && f.tail) {   // the engine's stream is the one the layout change's tail ran on; P's next panels read those columns
-            RFLU_HIP(hipStreamWaitEvent(P, f.tail, 0));
-            f.tail = nullptr;
-        }
-        RFLU_TRY(launch_eng_signal(h, &st->panel_done, (unsigned long long)b + 1, &st->cb[b].t_panel));
-    }
-    if (nbp < nblk) RFLU_TRY(launch_eng_wait(h, &st->cb[nbp].ready, 1));   // the next block column is somebody else's panel
-    // the engine leaves when every column block has received everything: evUend of the last block column = its end
-    RFLU_TRY(get_event(h, 4 * (size_t)std::max<int64_t>(nbp - 1, 0) + 3, &ev));
-    RFLU_HIP(hipEventRecord(ev, E));
-    if (E_out) *E_out = E;
-    if (nbp >= nblk) {
-        RFLU_HIP(hipStreamWaitEvent(P, ev, 0));
-        h->eng_active = false;
-    }
-    return RFLU_OK;
 }
 
 // Leaf-wise schedule: the critical path is nothing but the chain of cooperative leaves.
@@ -942,8 +860,13 @@ static int factor_engine(Fact<T>& f, int64_t W, int64_t b_end, hipStream_t* E_ou
 // S and U share the CU mask that keeps the panel's CUs free.  Every column receives the same eliminations in the same order
 // as in reckernel! (src/lu.jl:189-263); inside a block column the Schur complement is accumulated 64 pivots at a time instead
 // of in the recursion's growing chunks, so factors agree with the one-stream path to rounding, pivots exactly.
+// Engine mode (eng_end > 0, b_begin == 0): the side stream's and the update stream's work of block columns [0, eng_end) -- and the
+// block-column updates every column right of them needs from those -- is pulled by the persistent update engine (engine.hip) from
+// per-column-block counters instead of being enqueued on S and U; P is unchanged except that its lookahead launch waits for the
+// engine's progress word of the lookahead strip's column block instead of a side-stream gate.  From block column eng_end on the
+// streams take over again (short panels: the XCD-local leaves need CUs the resident engine does not give back).
 template <typename T>
-static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U_before)
+static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U_before, int64_t eng_end = 0)
 {
     Handle* h = f.h;
     const int64_t m = f.m, n = f.n, ld = f.ld, mn = std::min(m, n);
@@ -1031,15 +954,75 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         RFLU_HIP(hipMemset(h->gate_stamps, 0, 3 * 4096 * sizeof(long long)));
     }
     auto stamp = [&](int which, int64_t g) -> long long* { return (h->gate_stamps && g < 4096) ? h->gate_stamps + which * 4096 + g : nullptr; };
+    // ---- engine mode: state, launch ----
+    const int64_t LPB = W / NB;
+    EngGeo geo{};
+    EngState* est = nullptr;
+    hipStream_t E = nullptr;
+    struct RestoreLocal { Handle* h; int64_t rows; bool on; ~RestoreLocal() { if (on) h->tune.panel_local_rows = rows; } } restore_local{h, h->tune.panel_local_rows, false};
+    if (eng_end > 0) {
+        if (b_begin != 0) { set_error("factor_leafwise: the engine starts at block column 0"); return RFLU_ERR_ARG; }
+        eng_end = std::min(eng_end, nblk);
+        RFLU_TRY(get_ustream(h, 32, &E));
+        if (!h->eng_state) {
+            RFLU_HIP(hipMalloc(&h->eng_state, sizeof(EngState)));
+            RFLU_HIP(hipHostMalloc(&h->eng_host, sizeof(EngState), hipHostMallocDefault));
+        }
+        est = static_cast<EngState*>(h->eng_state);
+        EngState* img = static_cast<EngState*>(h->eng_host);
+        geo.m = (int)m; geo.n = (int)n; geo.mn = (int)mn; geo.W = (int)W; geo.nbp = (int)eng_end; geo.ncb = (int)((n + W - 1) / W);
+        geo.pivot = f.pivot;
+        const size_t bytes = offsetof(EngState, cb) + (size_t)geo.ncb * sizeof(EngCB);
+        memset(img, 0, bytes);
+        for (int cb = 0; cb < geo.ncb; ++cb) {
+            EngCB& c = img->cb[cb];
+            const int end = 2 * eng_nops(geo, cb);
+            int sq = 0;
+            while (sq < end && eng_units_of(eng_op(geo, cb, sq >> 1), sq & 1, geo.m) == 0) ++sq;
+            c.prog = (unsigned long long)(sq >> 1);
+            c.claim = sq < end ? (unsigned long long)sq << 32 : (unsigned long long)ENG_SEQ_DONE << 32;
+            img->remaining += sq < end;
+            const int nleft = eng_nleft(geo, cb);
+            int lk = 0;
+            while (lk < nleft && eng_left_units<T>(geo, cb, lk) == 0) ++lk;
+            c.lclaim = lk < nleft ? (unsigned long long)lk << 32 : (unsigned long long)ENG_SEQ_DONE << 32;
+            c.lprog = (unsigned long long)lk;   // (left ops without units count as done)
+            img->remaining += lk < nleft;
+        }
+        // the initial state travels on the caller's stream, in front of everything the engine is going to wait for
+        RFLU_HIP(hipMemcpyAsync(est, img, bytes, hipMemcpyHostToDevice, P));
+        RFLU_TRY(record_on(P, EX + (size_t)nblk + 1));
+        RFLU_TRY(wait_on(E, EX + (size_t)nblk + 1));
+        EngArgs<T> a;
+        a.R = R; a.ld = ld; a.g = geo; a.policy = h->tune.engine_policy;
+        a.linv = static_cast<const T*>(h->linv); a.pm_cnt = h->pm_cnt; a.pm_dst = h->pm_dst; a.pm_src = h->pm_src;
+        a.st = est; a.leaf_gate = h->gate_ptr[0]; a.gate_base = gbase; a.info = h->info_dev; a.gemm_flags = h->tune.gemm_flags;
+        for (int i = 0; i < 8; ++i) a.x[i] = h->tune.engine_x[i];
+        const int wgs = h->tune.engine_wgs > 0 ? h->tune.engine_wgs : 2 * (h->num_cus - 32);
+        if (img->remaining > 0) RFLU_TRY(launch_engine<T>(h, E, a, wgs));
+        RFLU_TRY(record_on(E, evUend(eng_end - 1)));   // the engine leaves when every column block has received everything it owes
+        h->eng_active = true;
+        // While the engine is resident the only CUs with room are the 4 per XCD its mask leaves out: the any-placement leaves (at most
+        // 32 workgroups, one per CU) fit there, the XCD-local ones (all participants on ONE XCD) would wait for CUs it never gives back
+        restore_local.on = true;
+        h->tune.panel_local_rows = 0;
+        Uprev = E;
+    }
     for (int64_t b = b_begin; b < nblk; ++b) {
+        const bool in_eng = b < eng_end;
+        if (eng_end > 0 && b == eng_end) {   // the streams take over: the leaves are short enough for the XCD-local exchange again
+            h->tune.panel_local_rows = restore_local.rows;
+            restore_local.on = false;
+        }
         const int64_t j0 = b * W, jb = std::min(W, mn - j0), je = j0 + jb;
         const int64_t bend = std::min(j0 + W, n), wend = std::min(j0 + 2 * W, n);
         const int res = reserve_for(m - j0);
         // The side stream is the update stream of the 64-CU reservation: it keeps away from the panel's 32 CUs like U does,
         // and a taller matrix has already used it for its first block columns -- one queue less to place (validate_queues).
         if (res != 32) { set_error("factor_leafwise: panel of %lld rows needs more than 32 CUs", (long long)(m - j0)); return RFLU_ERR_ARG; }
-        hipStream_t S;
-        RFLU_TRY(get_ustream(h, swap_s(b) ? 32 : 64, &S));
+        hipStream_t S = nullptr;
+        if (!in_eng) RFLU_TRY(get_ustream(h, swap_s(b) ? 32 : 64, &S));
+        if (!in_eng)
         {   // the critical path runs on the reserved CUs while the update stream is the bottleneck (see get_pstream)
             hipStream_t to = userS;
             if (m - j0 >= confine_rows && res == 32) RFLU_TRY(get_pstream(h, res, &to));
@@ -1056,14 +1039,27 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, f.ipiv, f.pivot));
             const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);
             const unsigned long long* wflag = nullptr;   // leaf g-1 reached LA through the side stream: in its own block's part, or the next block's
-            if (la1 > la0 && g > gfirst) wflag = h->gate_ptr[la0 < std::min(((c0 - NB) / W + 1) * W, n) ? 1 : 2];
+            unsigned long long wval = g > 0 ? val(g - 1) : 0;
+            if (la1 > la0 && g > gfirst) {
+                if (eng_end > 0 && (g - 1) / LPB < eng_end) {   // ... through the engine: LEAF(g - 1) is complete on the lookahead strip's column block
+                    const int cb_la = (int)(la0 / W);
+                    wflag = &est->cb[cb_la].prog;
+                    wval = (unsigned long long)eng_leaf_op_index(geo, cb_la, (int)(g - 1)) + 1;
+                } else {
+                    wflag = h->gate_ptr[la0 < std::min(((c0 - NB) / W + 1) * W, n) ? 1 : 2];
+                }
+            }
+            if (eng_end > 0 && f.tail && la1 > W) {   // the first launch of the critical path that touches the columns whose layout change
+                RFLU_HIP(hipStreamWaitEvent(P, f.tail, 0));   // ran on the engine's stream next to the first leaves
+                f.tail = nullptr;
+            }
             // one launch for {interchanges on LA, diagonal inverse, 64-row solve of LA}: full leaves with a full, 16-byte aligned LA
             const bool fuse = f.pivot && fold && h->tune.leaf_fuse && w == NB && la1 - la0 == NB && m - c0 > NB &&
                               reinterpret_cast<uintptr_t>(R) % 16 == 0 && ld % (16 / (int64_t)sizeof(T)) == 0;
             if (fuse) {
                 LaswpGate gt;
                 gt.wait_flag = wflag;
-                gt.wait_val = wflag ? val(g - 1) : 0;
+                gt.wait_val = wflag ? wval : 0;
                 gt.signal_flag = h->gate_ptr[0];
                 gt.signal_val = val(g);
                 gt.signal_cnt = reinterpret_cast<unsigned*>(h->gates + 4);
@@ -1073,23 +1069,25 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             } else if (f.pivot && fold) {   // both gates ride on the interchange launch: two launches less per leaf on this stream
                 LaswpGate gt;
                 gt.wait_flag = wflag;
-                gt.wait_val = wflag ? val(g - 1) : 0;
+                gt.wait_val = wflag ? wval : 0;
                 gt.signal_flag = h->gate_ptr[0];
                 gt.signal_val = val(g);
                 gt.signal_cnt = reinterpret_cast<unsigned*>(h->gates + 4);
                 gt.info = h->info_dev;
                 RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0), gt));
             } else {
-                if (wflag) RFLU_TRY(launch_gate_wait(h, wflag, val(g - 1)));
+                if (wflag) RFLU_TRY(launch_gate_wait(h, wflag, wval));
                 if (f.pivot) RFLU_TRY(launch_laswp2<T>(h, R, ld, la0, la1 - la0, 0, 0, c0 / NB, c0 / NB + 1, w, R + c0 * ld + c0, f.linv_at(c0)));
 
                 RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(g), stamp(0, g)));
             }
             if (!fuse) RFLU_TRY(apply_leaf(P, c0, w, la0, la1, false));
+            if (in_eng) continue;   // (the engine applies the leaf to the rest of this block column and to the next one)
             // ---- side stream: leaf g on the rest of this block column and on the next one ----
             h->stream = S;
             int rc = launch_gate_wait(h, h->gate_ptr[0], val(g));
-            if (rc == RFLU_OK && i == 0 && S != Sprev && g > gfirst) rc = launch_gate_wait(h, h->gate_ptr[2], val(g - 1));
+            if (rc == RFLU_OK && i == 0 && S != Sprev && g > gfirst && !(eng_end > 0 && (g - 1) / LPB < eng_end))
+                rc = launch_gate_wait(h, h->gate_ptr[2], val(g - 1));
             if (i == 0 && b > 0) {
                 // the next block column holds U(b-1)'s update only after evU1[b-1]; the critical path needs this block
                 // column's part first, so the leaf is applied in two pieces with a gate of its own in between.
@@ -1100,11 +1098,11 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                 h->stream = S;
                 if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g), stamp(1, g));
                 hipEvent_t e;
-                if (h->eng_active && b == b_begin) {
-                    // behind the update engine (factor_engine): the next block column is up to date when its ready word says so
-                    if (rc == RFLU_OK && b + 1 < (n + W - 1) / W) {
+                if (eng_end > 0 && b == eng_end) {
+                    // behind the update engine: the next block column is up to date when all its operations are complete
+                    if (rc == RFLU_OK && b + 1 < (n + W - 1) / W && eng_nops(geo, (int)(b + 1)) > 0) {
                         h->stream = S;
-                        rc = launch_eng_wait(h, &static_cast<EngState*>(h->eng_state)->cb[b + 1].ready, 1);
+                        rc = launch_eng_wait(h, &est->cb[b + 1].prog, (unsigned long long)eng_nops(geo, (int)(b + 1)));
                     }
                 } else {
                 if (rc == RFLU_OK) rc = get_event(h, evU1(b - 1), &e);
@@ -1122,6 +1120,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             h->stream = P;
             RFLU_TRY(rc);
         }
+        if (in_eng) continue;
         Sprev = S;
         // ---- U(b): everything right of block column b+1, and the interchanges nobody needed until now ----
         hipStream_t U;
@@ -1251,18 +1250,21 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
         if (W_wide > 0 && b_switch < nblk) wide_end = std::min(wide_end, std::max<int64_t>(b_switch - 1, 0) * Wb / W_wide * W_wide);
         hipStream_t U_last = nullptr;
         {
-            if (tail && b_switch == 0) {
+            // the update engine serves the block columns whose panels are taller than engine_rows (the leaf-wise schedule from block
+            // column 0, its side / update streams replaced by the engine); below that the streams and the XCD-local leaves take over
+            int64_t eng_end = 0;
+            if (leafwise && Wb >= 2 * NB && Wb <= 512 && W_wide == 0 && m <= 32 * (int64_t)PANEL_THREADS && engine_usable<T>(h, f, Wb)) {
+                const int64_t er = h->tune.engine_x[3] > 0 ? h->tune.engine_x[3] : 4096;   // RFLU_ENGINE_X3: panels taller than this go through the engine
+                eng_end = m <= er ? 0 : std::min(nblk, (m - er + Wb - 1) / Wb);
+            }
+            if (tail && b_switch == 0 && eng_end == 0) {
                 RFLU_HIP(hipStreamWaitEvent(h->stream, tail, 0));
                 tail = nullptr;
             }
             f.tail = tail;
-            if (b_switch > 0 && W_wide == 0 && engine_usable<T>(h, f, Wb)) {
-                if (tail) {   // the layout change's tail runs on the 224-CU stream: the engine is launched behind it on that stream
-                    hipStream_t E;
-                    RFLU_TRY(get_ustream(h, 32, &E));
-                    (void)E;
-                }
-                RFLU_TRY(factor_engine<T>(f, Wb, b_switch, &U_last));
+            if (eng_end > 0) {
+                RFLU_TRY(factor_leafwise<T>(f, Wb, 0, nullptr, eng_end));
+                b_switch = nblk;
             } else if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last, W_wide, wide_end));
             if (b_switch < nblk) RFLU_TRY(factor_leafwise<T>(f, Wb, b_switch, U_last));
         }
@@ -1771,7 +1773,7 @@ int rflu_debug_engine_times(rflu_handle_t handle, long long* t_ready, long long*
     if (!h->eng_state || n < 0 || n > ENG_MAX_CB) { set_error("no engine state (or n out of range)"); return RFLU_ERR_ARG; }
     std::vector<EngCB> tmp((size_t)n);
     RFLU_HIP(hipMemcpy(tmp.data(), static_cast<EngState*>(h->eng_state)->cb, (size_t)n * sizeof(EngCB), hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; ++i) { t_ready[i] = tmp[i].t_ready; t_panel[i] = tmp[i].t_panel; }
+    for (int i = 0; i < n; ++i) { t_ready[i] = tmp[i].t_ready; t_panel[i] = 0; }
     return RFLU_OK;
 }
 

@@ -8,18 +8,21 @@
 // own interchanges / solves run with the matrix cores idle (7 % of its time), and a block column's update cannot start before the
 // previous one has drained although only the SAME columns depend on each other.
 //
-// Design.  The trailing matrix is a set of COLUMN BLOCKS (W columns).  Column block cb has to receive the updates of panels
-// b = 0 .. cb-1 in that order, each as two stages ("sequences", seq = 2b + stage):
-//     stage 0: the interchanges of panel b on its columns + X = inv(L11) * A12       (units of 32 columns, one workgroup each)
+// Design.  The trailing matrix is a set of COLUMN BLOCKS (W columns).  Column block cb has to receive a fixed list of operations
+// in a fixed order (engine.hpp: eng_op) -- BIG(b): block column b as a whole (K = W) for every block column at least two to its
+// left, then LEAF(g): the eight leaves of the block column right in front of it and the leaves of its own block column, one at a
+// time (K = 64: the leaf-wise schedule's window, driver.cpp: factor_leafwise) -- each in two stages ("sequences", seq = 2 op + stage):
+//     stage 0: the operation's interchanges on its columns + X = inv(L11) * A12      (units of 32 columns, one workgroup each)
 //     stage 1: A22 -= A21 * X                                                        (units of one 128 x 128 tile)
 // and different column blocks are independent of each other.  Per column block a 64-bit claim word (seq << 32 | next unit) and a
 // done counter live in device memory; the 2 x (CUs of the mask) resident workgroups loop { scan the claim words (one lane per column
-// block) -> pick the eligible unit of highest priority -> fetch-and-add on its claim word -> agent-scope acquire -> run the unit ->
-// agent-scope release -> count it done; the last finisher of a sequence publishes the next one }.  A stage-0 sequence of panel b is
-// eligible once the critical-path stream has published panel_done > b; a column block that has received everything raises its
-// `ready` word, which the critical-path stream waits for in front of that block column's panel.  No workgroup ever waits for a
-// particular other workgroup: a unit is claimed only when everything it reads is final, so residency is a matter of speed, not of
-// correctness.  The interchanges that later panels owe the FINISHED column blocks to their left are units of lowest priority.
+// block) -> pick the eligible unit of highest priority (the leftmost column block: what the chain of leaves needs next) ->
+// fetch-and-add on its claim word -> agent-scope acquire -> run the unit -> agent-scope release -> count it done; the last finisher
+// of a sequence publishes the next one }.  An operation is eligible once the critical-path stream's leaf counter says that the
+// leaves it applies are factored (and their diagonal inverses / move lists written); a column block publishes how many of its
+// operations are complete (`prog`), which the critical-path stream waits for in front of a leaf's lookahead columns.  No workgroup
+// ever waits for a particular other workgroup: a unit is claimed when everything it reads is final, so residency is a matter of
+// speed, not of correctness.  The interchanges that later leaves owe the FINISHED columns to their left are units of lowest priority.
 // Inter-workgroup visibility follows MI355X_MICROARCH.md ("Workgroup dispatch ..."): producer = every wave drains its stores,
 // barrier, one lane's agent-scope release fence (buffer_wbl2 sc1) + s_waitcnt, then the counter; consumer = relaxed poll of the
 // claim word, one lane's agent-scope acquire (buffer_inv sc1), barrier, plain loads.
@@ -33,27 +36,13 @@
 
 namespace rflu {
 
-constexpr int EP_COLS = 32;             // columns of a stage-0 unit
+constexpr int EP_COLS = ENG_PREP_COLS;   // columns of a stage-0 unit
 constexpr int EP_XLD = EP_COLS + 16;    // LDS row pitch of the staged block (== 16 mod 32 doubles: conflict-free fragment reads)
 
 template <typename T>
 __device__ __forceinline__ int eng_units(const EngArgs<T>& a, int cb, unsigned seq)
 {
-    const int b = (int)(seq >> 1);
-    const int je = min(b * a.W + a.W, a.mn);
-    const int nc = min(a.W, a.n - cb * a.W);
-    if ((seq & 1u) == 0) return (nc + EP_COLS - 1) / EP_COLS;
-    const int rows = a.m - je;
-    if (rows <= 0) return 0;
-    return ((rows + G_BM - 1) / G_BM) * ((nc + G_BN - 1) / G_BN);
-}
-
-template <typename T>
-__device__ __forceinline__ int eng_left_units(const EngArgs<T>& a, int cb)
-{
-    constexpr int SC = 8 * (16 / (int)sizeof(T));
-    const int nc = min(a.W, a.n - cb * a.W);
-    return (nc + 4 * SC - 1) / (4 * SC);
+    return eng_units_of(eng_op(a.g, cb, (int)(seq >> 1)), (int)(seq & 1u), a.g.m);
 }
 
 __device__ __forceinline__ unsigned long long eng_load(const unsigned long long* p)
@@ -70,32 +59,31 @@ __device__ __forceinline__ void eng_release()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (MI355X_MICROARCH.md)
 }
 
-// ---- stage 0: interchanges of panel b on 32 columns of column block cb, then X = inv(L11) * A12 on those columns ----------------
+// ---- stage 0: the operation's interchanges on 32 of its columns, then X = inv(L11) * A12 on those columns ----------------------------
 // The solve is trsm_fused_kernel's left-looking walk over 64-row blocks with pre-inverted diagonal blocks (trsm.hip), for a block
 // row of any height: the solved blocks X_e are read back from memory (this workgroup's own stores, drained + barrier) instead of
-// being kept in LDS, so W = 512 ... 2048 rows cost 24 KB of LDS.  Wave w owns rows [16w, 16w+16) of a 64-row block x 32 columns.
+// being kept in LDS, so W = 512 ... 2048 rows cost 24 KB of LDS; a leaf (64 rows) is the loop's first round alone.  Wave w owns
+// rows [16w, 16w+16) of a 64-row block x 32 columns.
 template <typename T>
-__device__ __attribute__((noinline)) void eng_prep_unit(const EngArgs<T>& a, int cb, int b, int u, T* smem)
+__device__ __attribute__((noinline)) void eng_prep_unit(const EngArgs<T>& a, const EngOp o, int u, T* smem)
 {
     typedef typename Mfma<T>::acc_t acc_t;
     constexpr int VW = 16 / (int)sizeof(T);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j0 = b * a.W, je = min(j0 + a.W, a.mn), jb = je - j0;
-    const int ncb_cols = min(a.W, a.n - cb * a.W);
-    const int c0 = cb * a.W + u * EP_COLS;
-    const int nc = min(EP_COLS, ncb_cols - u * EP_COLS);
+    const int j0 = o.j0, jb = o.jb;
+    const int c0 = o.c_lo + u * EP_COLS;
+    const int nc = min(EP_COLS, o.nc - u * EP_COLS);
     T* const R = a.R;
     const int64_t ld = a.ld;
-    if (a.pivot) {
+    if (a.g.pivot) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const int chunk0 = j0 / NB, chunk1 = (je + NB - 1) / NB;
         if (nc % VW == 0) {
             constexpr int SC = 8 * VW;
             if (wv < (nc + SC - 1) / SC)
-                laswp_strip<T, VW, 8>(R, ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, wv);
+                laswp_strip<T, VW, 8>(R, ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, o.chunk0, o.chunk1, wv);
         } else {
             if (wv < (nc + 7) / 8)
-                laswp_strip<T, 1, 8>(R, ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, wv);
+                laswp_strip<T, 1, 8>(R, ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, o.chunk0, o.chunk1, wv);
         }
         __syncthreads();   // (every chunk of laswp_strip ends with s_waitcnt vmcnt(0): the rows are in place)
     }
@@ -169,22 +157,21 @@ __device__ __attribute__((noinline)) void eng_prep_unit(const EngArgs<T>& a, int
 
 // ---- stage 1: one 128 x 128 tile of A22 -= A21 * X --------------------------------------------------------------------------------
 template <typename T>
-__device__ __attribute__((noinline)) void eng_gemm_unit(const EngArgs<T>& a, int cb, int b, int t, T* smem)
+__device__ __attribute__((noinline)) void eng_gemm_unit(const EngArgs<T>& a, const EngOp o, int t, T* smem)
 {
     constexpr int VW = 16 / (int)sizeof(T);
-    const int j0 = b * a.W, je = min(j0 + a.W, a.mn);
-    const int cc = cb * a.W;
+    const int je = o.j0 + o.jb;
     GemmArgs<T> g;
-    g.M = a.m - je;
-    g.N = min(a.W, a.n - cc);
-    g.K = je - j0;
-    g.A = a.R + (int64_t)je * a.ld + j0;
-    g.B = a.R + (int64_t)j0 * a.ld + cc;
-    g.C = a.R + (int64_t)je * a.ld + cc;
+    g.M = a.g.m - je;
+    g.N = o.nc;
+    g.K = o.jb;
+    g.A = a.R + (int64_t)je * a.ld + o.j0;
+    g.B = a.R + (int64_t)o.j0 * a.ld + o.c_lo;
+    g.C = a.R + (int64_t)je * a.ld + o.c_lo;
     g.lda = g.ldb = g.ldc = a.ld;
     g.tiles_m = (g.M + G_BM - 1) / G_BM;
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
-    g.vec_ok = (reinterpret_cast<uintptr_t>(a.R) % 16 == 0) && (a.ld % VW == 0);
+    g.vec_ok = (reinterpret_cast<uintptr_t>(a.R) % 16 == 0) && (a.ld % VW == 0) && (o.c_lo % VW == 0) && (o.j0 % VW == 0);
     g.flags = a.gemm_flags;
     g.na_tiles_n = 0; g.sig_flag = nullptr; g.sig_val = 0; g.sig_cnt = nullptr;
     // G_GROUP_M tile rows are walked together, column after column: consecutive claims share the B panel, then the A panels
@@ -201,21 +188,34 @@ __device__ __attribute__((noinline)) void eng_gemm_unit(const EngArgs<T>& a, int
     else gemm_tile<T, true, false>(g, smem, m0, n0);
 }
 
-// ---- deferred interchanges of panel b on the finished column block cb (to the left of the panel): 4 wave strips per unit ----------
+// ---- deferred interchanges on the finished column block cb.  Left op 0: unit u = the 64 columns of the block column's leaf u, which
+// still owe the interchanges of the leaves behind it in the same block column; left op lk >= 1: block column cb + lk as a whole, four
+// wave strips (of one 128-byte line per row) per unit
 template <typename T>
-__device__ __attribute__((noinline)) void eng_left_unit(const EngArgs<T>& a, int cb, int b, int u)
+__device__ __attribute__((noinline)) void eng_left_unit(const EngArgs<T>& a, int cb, int lk, int u)
 {
     constexpr int VW = 16 / (int)sizeof(T);
     constexpr int SC = 8 * VW;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j0 = b * a.W, je = min(j0 + a.W, a.mn);
-    const int ncb_cols = min(a.W, a.n - cb * a.W);
-    const int c0 = cb * a.W + u * 4 * SC;
-    const int nc = min(4 * SC, ncb_cols - u * 4 * SC);
-    const int chunk0 = j0 / NB, chunk1 = (je + NB - 1) / NB;
+    const int LPB = a.g.W / NB;
+    const int cb0 = cb * a.g.W;
+    const int ncb_cols = min(a.g.W, a.g.n - cb0);
+    int c0, nc, chunk0, chunk1;
+    if (lk == 0) {
+        c0 = cb0 + u * NB;
+        nc = min(NB, ncb_cols - u * NB);
+        chunk0 = cb * LPB + u + 1;
+        chunk1 = cb * LPB + eng_leaves_of_block(a.g, cb);
+    } else {
+        c0 = cb0 + u * 4 * SC;
+        nc = min(4 * SC, ncb_cols - u * 4 * SC);
+        chunk0 = (cb + lk) * LPB;
+        chunk1 = chunk0 + eng_leaves_of_block(a.g, cb + lk);
+    }
+    if (nc <= 0 || chunk1 <= chunk0) return;
     if (nc % VW == 0) {
-        if (wave < (nc + SC - 1) / SC)
-            laswp_strip<T, VW, 8>(a.R, a.ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, wave);
+        for (int s = wave; s < (nc + SC - 1) / SC; s += 4)
+            laswp_strip<T, VW, 8>(a.R, a.ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, s);
     } else {
         for (int s = wave; s < (nc + 7) / 8; s += 4)
             laswp_strip<T, 1, 8>(a.R, a.ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, s);
@@ -234,6 +234,12 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
     const int tid = threadIdx.x, lane = tid & 63;
     long long idle_since = -1;
     int idle_rounds = 0;
+    int cb_lo = 0;             // column blocks in front of this one have nothing left for the main scan (monotone)
+
+    auto leaves_done = [&]() -> int {
+        const unsigned long long v = eng_load(a.leaf_gate);
+        return v > a.gate_base ? (int)(v - a.gate_base) : 0;
+    };
 
     for (;;) {
         if (tid < 64) {
@@ -241,26 +247,36 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
             unsigned sel_seq = 0;
             for (int attempt = 0; attempt < 4 && kind == ENG_NONE; ++attempt) {
                 if (eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0) { kind = ENG_EXIT; break; }
-                const unsigned long long pd = eng_load(&st->panel_done);
+                const int pd = leaves_done();
                 // ---- main units: one lane per column block -----------------------------------------------------------------
                 int best = INT_MAX;
-                for (int base = 0; base < a.ncb; base += 64) {
+                int first_live = INT_MAX;
+                for (int base = cb_lo & ~63; base < a.g.ncb; base += 64) {
                     const int cb = base + lane;
                     int key = INT_MAX;
-                    unsigned long long w = 0;
-                    if (cb < a.ncb) {
-                        w = eng_load(&st->cb[cb].claim);
+                    bool live = false;
+                    if (cb < a.g.ncb) {
+                        const unsigned long long w = eng_load(&st->cb[cb].claim);
                         const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
                         if (seq != ENG_SEQ_DONE) {
-                            const int b = (int)(seq >> 1);
-                            if ((unsigned long long)b < pd && (int)u < eng_units(a, cb, seq)) key = a.policy ? cb : ((b << 10) | cb);
+                            live = true;
+                            const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+                            bool ok = o.need <= pd && (int)u < eng_units_of(o, (int)(seq & 1u), a.g.m);
+                            // a block column as a whole is applied with ITS interchanges complete on all its columns (engine.hpp)
+                            if (ok && o.type == ENG_OP_BIG && (seq & 1u) == 0 && eng_big_waits_for_left(a.g, (int)(seq >> 1)))
+                                ok = eng_load(&st->cb[seq >> 1].lprog) >= 1;
+                            if (ok) key = a.policy ? (((o.j0 / NB) << 10) | cb) : cb;
                         }
                     }
+                    const unsigned long long lv = __ballot(live);
+                    if (lv != 0 && first_live == INT_MAX) first_live = base + __ffsll((long long)lv) - 1;
                     int mk = key;
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
                     best = min(best, mk);
+                    if (a.policy == 0 && best != INT_MAX) break;   // leftmost first: nothing further right can beat it
                 }
+                if (first_live != INT_MAX) cb_lo = first_live;
                 if (best != INT_MAX) {
                     // fetch-and-add, not compare-and-swap: with a few hundred workgroups arriving together a CAS hands out ONE unit per
                     // round trip (the losers rescan: 384 tiles took 0.6 ms to hand out).  Whatever (sequence, unit) the add returns is
@@ -270,33 +286,45 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     if (lane == 0) w = __hip_atomic_fetch_add(&st->cb[cb].claim, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     w = __shfl(w, 0);
                     const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
-                    if (seq != ENG_SEQ_DONE && (int)u < eng_units(a, cb, seq)) {
-                        kind = ENG_MAIN; sel_cb = cb; sel_seq = seq; sel_unit = (int)u;
-                        // The scan saw an eligible sequence; the add may have landed in a LATER one (published in between).  A later
-                        // stage 1 is ready by construction; a later stage 0 needs its panel -- practically never the case (a whole
-                        // sequence would have to complete between this wave's scan and its add), but then the claim is held until
-                        // the panel is there (bounded; the panel does not depend on this workgroup)
-                        if ((seq & 1u) == 0) {
-                            const long long t0 = wall_clock64();
-                            while (eng_load(&st->panel_done) <= (unsigned long long)(seq >> 1) && eng_load(&st->abort) == 0) {
-                                __builtin_amdgcn_s_sleep(16);
-                                if (wall_clock64() - t0 > 400000000LL) break;   // (the idle timeout of the others raises the flag)
+                    if (seq != ENG_SEQ_DONE) {
+                        const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+                        if ((int)u < eng_units_of(o, (int)(seq & 1u), a.g.m)) {
+                            kind = ENG_MAIN; sel_cb = cb; sel_seq = seq; sel_unit = (int)u;
+                            // The scan saw an eligible sequence; the add may have landed in a LATER one (published in between).  A later
+                            // stage 1 is ready by construction; a later stage 0 needs its leaves -- practically never the case (a whole
+                            // sequence would have to complete between this wave's scan and its add), but then the claim is held until
+                            // they are there (bounded; the leaves do not depend on this workgroup)
+                            if ((seq & 1u) == 0) {
+                                const long long t0 = wall_clock64();
+                                const bool wl = o.type == ENG_OP_BIG && eng_big_waits_for_left(a.g, (int)(seq >> 1));
+                                while ((leaves_done() < o.need || (wl && eng_load(&st->cb[seq >> 1].lprog) < 1)) && eng_load(&st->abort) == 0) {
+                                    __builtin_amdgcn_s_sleep(16);
+                                    if (wall_clock64() - t0 > 400000000LL) break;   // (the idle timeout of the others raises the flag)
+                                }
                             }
                         }
                     }
                     continue;   // (past the end: look again)
                 }
-                // ---- deferred interchanges to the left of the panels ------------------------------------------------------
-                if (a.pivot) {
+                // ---- deferred interchanges on the finished column blocks ---------------------------------------------------
+                if (a.g.pivot) {
                     int bestl = INT_MAX;
-                    for (int base = 0; base < a.ncb; base += 64) {
+                    for (int base = 0; base < a.g.nbp; base += 64) {
                         const int cb = base + lane;
                         int key = INT_MAX;
-                        unsigned long long w = 0;
-                        if (cb < a.ncb) {
-                            w = eng_load(&st->cb[cb].lclaim);
-                            const unsigned b = (unsigned)(w >> 32), u = (unsigned)w;
-                            if (b != ENG_SEQ_DONE && (unsigned long long)b < pd && (int)u < eng_left_units(a, cb)) key = ((int)b << 10) | cb;
+                        if (cb < a.g.nbp) {
+                            const unsigned long long w = eng_load(&st->cb[cb].lclaim);
+                            const unsigned lk = (unsigned)(w >> 32), u = (unsigned)w;
+                            if (lk != ENG_SEQ_DONE && eng_left_need(a.g, cb, (int)lk) <= pd && (int)u < eng_left_units<T>(a.g, cb, (int)lk)) {
+                                bool ok;
+                                if (lk == 0) {   // every LEAF op of this block column is complete: here and on the column block to the right
+                                    ok = (unsigned)(eng_load(&st->cb[cb].claim) >> 32) == ENG_SEQ_DONE &&
+                                         (cb + 1 >= a.g.ncb || (int)eng_load(&st->cb[cb + 1].prog) >= eng_leafn_end(a.g, cb + 1));
+                                } else {         // nobody reads this block column's L any more
+                                    ok = (int)eng_load(&st->cb[cb].bigdone) >= eng_big_users(a.g, cb);
+                                }
+                                if (ok) key = ((int)lk << 10) | cb;
+                            }
                         }
                         int mk = key;
 #pragma unroll
@@ -308,11 +336,19 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         unsigned long long w = 0;
                         if (lane == 0) w = __hip_atomic_fetch_add(&st->cb[cb].lclaim, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         w = __shfl(w, 0);
-                        const unsigned b = (unsigned)(w >> 32), u = (unsigned)w;
-                        if (b != ENG_SEQ_DONE && (int)u < eng_left_units(a, cb)) {
-                            kind = ENG_LEFT; sel_cb = cb; sel_seq = b; sel_unit = (int)u;
+                        const unsigned lk = (unsigned)(w >> 32), u = (unsigned)w;
+                        if (lk != ENG_SEQ_DONE && (int)u < eng_left_units<T>(a.g, cb, (int)lk)) {
+                            kind = ENG_LEFT; sel_cb = cb; sel_seq = lk; sel_unit = (int)u;
                             const long long t0 = wall_clock64();
-                            while (eng_load(&st->panel_done) <= (unsigned long long)b && eng_load(&st->abort) == 0) {
+                            // (a later left op than the one the scan saw: its own conditions, see the scan)
+                            auto left_ok = [&]() -> bool {
+                                if (leaves_done() < eng_left_need(a.g, cb, (int)lk)) return false;
+                                if (lk == 0)
+                                    return (unsigned)(eng_load(&st->cb[cb].claim) >> 32) == ENG_SEQ_DONE &&
+                                           (cb + 1 >= a.g.ncb || (int)eng_load(&st->cb[cb + 1].prog) >= eng_leafn_end(a.g, cb + 1));
+                                return (int)eng_load(&st->cb[cb].bigdone) >= eng_big_users(a.g, cb);
+                            };
+                            while (!left_ok() && eng_load(&st->abort) == 0) {
                                 __builtin_amdgcn_s_sleep(16);
                                 if (wall_clock64() - t0 > 400000000LL) break;
                             }
@@ -342,7 +378,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 }
                 break;
             }
-            idle_rounds = min(idle_rounds + 1, 16);
+            idle_rounds = min(idle_rounds + 1, 8);
             for (int i = 0; i < idle_rounds; ++i) __builtin_amdgcn_s_sleep(32);
             __syncthreads();   // s_sel is rewritten by wave 0 in the next round
             continue;
@@ -350,9 +386,9 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         idle_since = -1;
         idle_rounds = 0;
         if (kind == ENG_MAIN) {
-            const int b = (int)(seq >> 1);
-            if ((seq & 1u) == 0) eng_prep_unit<T>(a, cb, b, unit, smem);
-            else eng_gemm_unit<T>(a, cb, b, unit, smem);
+            const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+            if ((seq & 1u) == 0) eng_prep_unit<T>(a, o, unit, smem);
+            else eng_gemm_unit<T>(a, o, unit, smem);
         } else {
             eng_left_unit<T>(a, cb, (int)seq, unit);
         }
@@ -368,13 +404,18 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 if ((int)d == units) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                     eng_store(&c->done, 0ull);
-                    const unsigned end = 2u * (unsigned)min(cb, a.nbp);
+                    const unsigned end = 2u * (unsigned)eng_nops(a.g, cb);
                     unsigned ns = seq + 1;
-                    while (ns < end && eng_units(a, cb, ns) == 0) ++ns;
+                    while (ns < end && eng_units(a, cb, ns) == 0) ++ns;   // (an operation with no columns left, a panel with no rows below it)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if ((ns >> 1) != (seq >> 1)) {
+                        for (unsigned k = seq >> 1; k < (ns >> 1); ++k)   // (the operations just completed, skipped ones included)
+                            if ((int)k < eng_nbig(a.g, cb))
+                                __hip_atomic_fetch_add(&st->cb[k].bigdone, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&c->prog, (unsigned long long)(ns >> 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     if (ns >= end) {
                         c->t_ready = wall_clock64();
-                        __hip_atomic_store(&c->ready, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&c->claim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
@@ -382,18 +423,21 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     }
                 }
             } else {
-                const int units = eng_left_units(a, cb);
+                const int units = eng_left_units<T>(a.g, cb, (int)seq);
                 const unsigned long long d = __hip_atomic_fetch_add(&c->ldone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
                 if ((int)d == units) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                     eng_store(&c->ldone, 0ull);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned nb = seq + 1;
-                    if ((int)nb >= a.nbp) {
+                    const int nleft = eng_nleft(a.g, cb);
+                    int nk = (int)seq + 1;
+                    while (nk < nleft && eng_left_units<T>(a.g, cb, nk) == 0) ++nk;
+                    __hip_atomic_store(&c->lprog, (unsigned long long)nk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (nk >= nleft) {
                         __hip_atomic_store(&c->lclaim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
-                        __hip_atomic_store(&c->lclaim, (unsigned long long)nb << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&c->lclaim, (unsigned long long)nk << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -425,13 +469,6 @@ template int launch_engine<double>(Handle*, hipStream_t, const EngArgs<double>&,
 template int launch_engine<float>(Handle*, hipStream_t, const EngArgs<float>&, int);
 
 // ---- the critical-path stream's side of the protocol ---------------------------------------------------------------------------------
-__global__ void eng_signal_kernel(unsigned long long* flag, unsigned long long value, long long* stamp)
-{
-    // (the kernels in front of this one on the stream have completed: their data is in memory)
-    if (stamp) *stamp = wall_clock64();
-    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 __global__ void eng_wait_kernel(const unsigned long long* flag, unsigned long long value, unsigned long long* abort, int64_t* info)
 {
     const long long t0 = wall_clock64();
@@ -445,13 +482,6 @@ __global__ void eng_wait_kernel(const unsigned long long* flag, unsigned long lo
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-int launch_eng_signal(Handle* h, unsigned long long* flag, unsigned long long value, long long* stamp)
-{
-    hipLaunchKernelGGL(eng_signal_kernel, dim3(1), dim3(1), 0, h->stream, flag, value, stamp);
-    RFLU_HIP(hipGetLastError());
-    return RFLU_OK;
 }
 
 int launch_eng_wait(Handle* h, const unsigned long long* flag, unsigned long long value)

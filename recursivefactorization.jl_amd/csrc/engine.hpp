@@ -1,63 +1,203 @@
-// engine.hpp -- the persistent update engine (engine.hip): state shared between the host schedule (driver.cpp: factor_engine)
-// and the device.  See engine.hip for the design.
+// engine.hpp -- the persistent update engine (engine.hip): state and work description shared between the host schedule
+// (driver.cpp: factor_leafwise in engine mode) and the device.  See engine.hip for the design.
 #pragma once
 
 #include <stdint.h>
 
 #include "rflu_internal.hpp"
 
+#if defined(__HIPCC__)
+#define RFLU_HD __host__ __device__ __forceinline__
+#else
+#define RFLU_HD inline
+#endif
+
 namespace rflu {
 
 constexpr int ENG_MAX_CB = 512;                       // column blocks a factorization may have
 constexpr unsigned ENG_SEQ_DONE = 0x7fffffffu;        // claim word of a column block that has received everything
+constexpr int ENG_PREP_COLS = 32;                     // columns of a stage-0 unit
 
-// One per column block (64 bytes).  A "sequence" is one stage of one block column's update: seq = 2*b + stage, stage 0 = the
-// interchanges of panel b on this column block + the block-row solve, stage 1 = the Schur update tiles.
+// One per column block (64 bytes).  A column block receives a fixed SEQUENCE OF OPERATIONS (EngOp below), each in two stages:
+// seq = 2 * op + stage, stage 0 = interchanges + block-row solve (units of 32 columns), stage 1 = Schur update (128 x 128 tiles).
 struct EngCB {
     unsigned long long claim;    // (seq << 32) | next unclaimed unit of that sequence
     unsigned long long done;     // finished units of the current sequence
-    unsigned long long lclaim;   // deferred interchanges of LATER panels on this (finished) column block: (b << 32) | next unit
+    unsigned long long lclaim;   // deferred interchanges on this (finished) column block: (left op << 32) | next unit
     unsigned long long ldone;
-    unsigned long long ready;    // != 0: every update of the panels in front of this column block has been applied
-    long long t_ready;           // wall clock (100 MHz) when `ready` was raised / when the panel of this block column was
-    long long t_panel;           // published (rflu_debug_engine_times)
-    unsigned long long pad[1];
+    unsigned long long prog;     // operations completed (the critical-path stream waits for prog > op in front of a leaf's lookahead columns)
+    long long t_ready;           // wall clock (100 MHz) when the last operation completed (rflu_debug_engine_times)
+    unsigned long long lprog;    // left operations completed (lprog >= 1: the block column's own later interchanges have reached all its columns)
+    unsigned long long bigdone;  // column blocks that have completed BIG(this block column)
 };
 
 struct EngState {
-    unsigned long long panel_done;   // panels [0, panel_done) are factored (written by the critical-path stream)
+    unsigned long long unused0;
     unsigned long long remaining;    // column-block sequences (main and left) still unfinished: the engine exits at 0
     unsigned long long abort;        // != 0: leave (timeout somewhere)
     unsigned long long pad[5];
     EngCB cb[ENG_MAX_CB];
 };
 
+// Geometry of the schedule (plain integers: host and device compute the same operation lists from it)
+struct EngGeo {
+    int m, n, mn;
+    int W;          // block-column width (a multiple of 128)
+    int nbp;        // the engine serves the leaves of block columns [0, nbp)
+    int ncb;        // column blocks of width W covering [0, n)
+    int pivot;
+};
+
+enum { ENG_OP_BIG = 0, ENG_OP_LEAF = 1 };
+
+// One operation on a column block: apply the pivot block [j0, j0 + jb) x [j0, j0 + jb) (+ the rows below) to columns [c_lo, c_lo + nc)
+struct EngOp {
+    int type;
+    int j0, jb;     // pivot rows / columns of the applied panel piece
+    int c_lo, nc;   // columns that receive it (nc <= 0: nothing to do -- the operation completes by itself)
+    int need;       // leaves [0, need) must be factored AND their lookahead launch must have run (diagonal inverse, move list)
+    int chunk0, chunk1;   // pivot chunks (64 pivots each) whose interchanges belong to it
+};
+
+RFLU_HD int eng_leaves_of_block(const EngGeo& g, int b)
+{
+    const int j0 = b * g.W;
+    const int jb = g.mn - j0 < g.W ? g.mn - j0 : g.W;
+    return jb <= 0 ? 0 : (jb + NB - 1) / NB;
+}
+
+// operations of column block cb, in order:
+//   BIG(b),  b = 0 .. min(cb - 1, nbp) - 1 : block column b as a whole (K = W) -- block columns at least two to the left
+//   LEAF(g), g = leaves of block column cb - 1 (if that one is served): K = 64, the leaf-wise schedule's "next block column" window
+//   LEAF(g), g = leaves of block column cb itself but its last (if served): K = 64 on the columns right of the leaf's lookahead strip
+RFLU_HD int eng_nbig(const EngGeo& g, int cb)
+{
+    int v = cb - 1;
+    if (v < 0) v = 0;
+    return v < g.nbp ? v : g.nbp;
+}
+RFLU_HD int eng_nleafn(const EngGeo& g, int cb) { return (cb >= 1 && cb - 1 < g.nbp) ? eng_leaves_of_block(g, cb - 1) : 0; }
+RFLU_HD int eng_nleafo(const EngGeo& g, int cb)
+{
+    if (cb >= g.nbp) return 0;
+    const int nl = eng_leaves_of_block(g, cb);
+    return nl > 1 ? nl - 1 : 0;
+}
+RFLU_HD int eng_nops(const EngGeo& g, int cb) { return eng_nbig(g, cb) + eng_nleafn(g, cb) + eng_nleafo(g, cb); }
+
+RFLU_HD EngOp eng_op(const EngGeo& g, int cb, int k)
+{
+    EngOp o;
+    const int LPB = g.W / NB;
+    const int cb0 = cb * g.W;
+    const int cb_end = cb0 + g.W < g.n ? cb0 + g.W : g.n;
+    const int nbig = eng_nbig(g, cb);
+    if (k < nbig) {
+        o.type = ENG_OP_BIG;
+        o.j0 = k * g.W;
+        o.jb = g.mn - o.j0 < g.W ? g.mn - o.j0 : g.W;
+        o.c_lo = cb0;
+        o.nc = cb_end - cb0;
+        o.chunk0 = o.j0 / NB;
+        o.chunk1 = (o.j0 + o.jb + NB - 1) / NB;
+        o.need = o.chunk1;
+        return o;
+    }
+    const int nln = eng_nleafn(g, cb);
+    int leaf;
+    if (k - nbig < nln) leaf = (cb - 1) * LPB + (k - nbig);
+    else leaf = cb * LPB + (k - nbig - nln);
+    o.type = ENG_OP_LEAF;
+    o.j0 = leaf * NB;
+    o.jb = g.mn - o.j0 < NB ? g.mn - o.j0 : NB;
+    const int la1 = o.j0 + o.jb + NB;   // the leaf's lookahead strip [j0 + jb, la1) is the critical-path stream's own business
+    o.c_lo = la1 > cb0 ? la1 : cb0;
+    o.nc = cb_end - o.c_lo;
+    o.chunk0 = leaf;
+    o.chunk1 = leaf + 1;
+    o.need = leaf + 1;
+    return o;
+}
+
+// index of LEAF(leaf) in column block cb's operation list (cb = the leaf's own block column or the one right of it)
+RFLU_HD int eng_leaf_op_index(const EngGeo& g, int cb, int leaf)
+{
+    const int LPB = g.W / NB;
+    const int lb = leaf / LPB;
+    if (lb == cb - 1) return eng_nbig(g, cb) + (leaf - lb * LPB);
+    return eng_nbig(g, cb) + eng_nleafn(g, cb) + (leaf - cb * LPB);
+}
+
+// ---- deferred interchanges on finished column blocks (cb < nbp): left op 0 = the later leaves of the block column itself on the
+// columns of its earlier leaves (one unit per 64-column strip), left op i >= 1 = block column cb + i as a whole
+RFLU_HD int eng_nleft(const EngGeo& g, int cb)
+{
+    if (!g.pivot || cb >= g.nbp) return 0;
+    return 1 + (g.nbp - 1 - cb);
+}
+RFLU_HD int eng_left_need(const EngGeo& g, int cb, int lk)
+{
+    const int b = cb + lk;
+    return b * (g.W / NB) + eng_leaves_of_block(g, b);
+}
+template <typename T>
+RFLU_HD int eng_left_units(const EngGeo& g, int cb, int lk)
+{
+    const int cb0 = cb * g.W;
+    const int nc = (cb0 + g.W < g.n ? cb0 + g.W : g.n) - cb0;
+    if (lk == 0) {
+        const int nl = eng_leaves_of_block(g, cb);
+        return nl > 1 ? nl - 1 : 0;
+    }
+    constexpr int SC4 = 4 * 8 * (16 / (int)sizeof(T));   // four wave strips of one 128-byte line per row
+    return (nc + SC4 - 1) / SC4;
+}
+
+RFLU_HD int eng_units_of(const EngOp& o, int stage, int m)
+{
+    if (o.nc <= 0) return 0;
+    if (stage == 0) return (o.nc + ENG_PREP_COLS - 1) / ENG_PREP_COLS;
+    const int rows = m - (o.j0 + o.jb);
+    if (rows <= 0) return 0;
+    return ((rows + 127) / 128) * ((o.nc + 127) / 128);
+}
+
+// ---- order between the interchanges and the readers of a panel ------------------------------------------------------------------
+// The leaves of block column b are applied one by one (LEAF ops on column blocks b and b + 1) with the rows of L in the order of
+// THAT leaf; the block column as a whole (BIG(b), column blocks b + 2 ...) needs L with all of the block column's interchanges
+// applied (left op 0 of column block b), and the interchanges of later block columns may permute L(b) only when nobody reads it
+// any more:
+//   left op 0 of b     after  every LEAF op of block column b is complete (column blocks b and b + 1)
+//   BIG(b) anywhere    after  left op 0 of b                                  (lprog[b] >= 1)
+//   left op >= 1 of b  after  BIG(b) is complete on every column block that has it   (bigdone[b] == eng_big_users(b))
+RFLU_HD bool eng_big_waits_for_left(const EngGeo& g, int b) { return g.pivot && eng_leaves_of_block(g, b) > 1; }
+RFLU_HD int eng_big_users(const EngGeo& g, int b)
+{
+    const int v = g.ncb - (b + 2);
+    return (b < g.nbp && v > 0) ? v : 0;
+}
+RFLU_HD int eng_leafn_end(const EngGeo& g, int cb) { return eng_nbig(g, cb) + eng_nleafn(g, cb); }   // ops of cb up to its LEAF ops of block column cb - 1
+
 template <typename T>
 struct EngArgs {
     T* R;
     int64_t ld;
-    int m, n, mn;
-    int W;          // block-column width (a multiple of 128)
-    int nbp;        // the engine applies panels [0, nbp)
-    int ncb;        // column blocks of width W covering [0, n)
-    int pivot;
-    int policy;     // 0: oldest panel first (right-looking order); 1: leftmost column block first
+    EngGeo g;
+    int policy;     // 0: leftmost column block first; 1: oldest panel piece first
     const T* linv;  // inverses of the 64x64 diagonal blocks, one per 64 rows
     const int* pm_cnt;
     const int* pm_dst;
     const int* pm_src;
     EngState* st;
+    const unsigned long long* leaf_gate;   // the critical-path stream's counter: gate_base + (leaves completed incl. their lookahead launch)
+    unsigned long long gate_base;
     int64_t* info;  // info[1] bit 0: timeout
     int gemm_flags;
     int x[8];       // experiment switches (Tune::engine_x)
 };
 
-// host-side mirror of the device's unit counts (driver.cpp initialises the state with them)
-inline int eng_nseq(int cb, int nbp) { return 2 * (cb < nbp ? cb : nbp); }
-
 template <typename T>
 int launch_engine(Handle* h, hipStream_t stream, const EngArgs<T>& a, int wgs);
-int launch_eng_signal(Handle* h, unsigned long long* flag, unsigned long long value, long long* stamp = nullptr);
 int launch_eng_wait(Handle* h, const unsigned long long* flag, unsigned long long value);
 size_t engine_lds_bytes(size_t esize);
 

@@ -52,38 +52,31 @@ def compare(n, sfx, bs, env_extra=None, m=None, pivot=1):
 
 if mode in ("quick", "all"):
     allok = True
-    lw0 = {"RFLU_LEAFWISE": "0"}
-    for n, bs in [(1024, 256), (2048, 512), (3000, 256), (4096, 512), (2048, 128), (5000, 512), (8192, 512)]:
-        allok &= compare(n, "f64", bs, lw0)
-    allok &= compare(4096, "f32", 512, lw0)
-    allok &= compare(3000, "f32", 256, lw0)
-    allok &= compare(4096, "f64", 512, lw0, pivot=0)
-    allok &= compare(3072, "f64", 512, lw0, m=5000)            # tall
-    allok &= compare(5120, "f64", 512, lw0, m=3072)            # fat, m a multiple of W
-    allok &= compare(12288, "f64", 0)                          # engine part + leaf-wise part behind it
-    allok &= compare(4096, "f64", 512, {"RFLU_LEAFWISE": "0", "RFLU_ENGINE_POLICY": "1"})
+    for n, bs in [(5000, 0), (6144, 256), (8192, 0), (8192, 512), (10000, 0), (12288, 0), (6000, 128)]:
+        allok &= compare(n, "f64", bs)
+    allok &= compare(8192, "f32", 0)
+    allok &= compare(12288, "f32", 0)
+    allok &= compare(8192, "f64", 0, pivot=0)
+    allok &= compare(6144, "f64", 512, m=10000)            # tall
+    allok &= compare(10240, "f64", 512, m=6144)            # fat, m a multiple of W
+    allok &= compare(8192, "f64", 0, {"RFLU_ENGINE_POLICY": "1"})
+    allok &= compare(8192, "f64", 0, {"RFLU_ENGINE_X3": "1024"})   # engine down to 1024-row panels
+    allok &= compare(16384, "f64", 0)
     print("ALL OK" if allok else "FAILURES", flush=True)
 
 if mode in ("time", "all"):
     for n in (8192, 12288, 16384):
         for env in ({"RFLU_ENGINE": "0"}, {"RFLU_ENGINE": "1"}, {"RFLU_ENGINE": "1", "RFLU_ENGINE_POLICY": "1"},
-                    {"RFLU_ENGINE": "0", "RFLU_LEAFWISE": "0"}, {"RFLU_ENGINE": "1", "RFLU_LEAFWISE": "0"},
-                    {"RFLU_ENGINE": "1", "RFLU_LEAFWISE": "0", "RFLU_ENGINE_POLICY": "1"}):
+                    {"RFLU_ENGINE": "1", "RFLU_ENGINE_X3": "2048"}, {"RFLU_ENGINE": "1", "RFLU_ENGINE_X3": "6144"}):
             _, _, _, info, t = factor(n, "f64", 0, env, reps=4)
             print(f"n={n} {env}: info {info} best {t:.2f} ms", flush=True)
 
 if mode in ("trace", "all"):
-    # per block column: when its panel could start (column block ready), when the panel was done, and the update latency behind it
-    for n, env in ((16384, {"RFLU_ENGINE": "1"}), (16384, {"RFLU_ENGINE": "1", "RFLU_ENGINE_POLICY": "1"}), (16384, {"RFLU_ENGINE": "1", "RFLU_LEAFWISE": "0"})):
+    # per column block: when it had received everything the engine owes it (us since the first one)
+    for n, env in ((16384, {"RFLU_ENGINE": "1"}),):
         _, _, _, info, t = factor(n, "f64", 0, env, reps=2)
         nb = n // 512
         tr = (ctypes.c_longlong * nb)(); tp = (ctypes.c_longlong * nb)()
         h.call("rflu_debug_engine_times", tr, tp, nb)
-        t0 = tp[0]
-        print(f"n={n} {env}: {t:.2f} ms; per block column [us since panel 0 done]: ready, panel done, panel time, update latency")
-        for b in range(nb):
-            if tp[b] == 0:
-                break
-            rdy = (tr[b] - t0) / 100.0 if b > 0 else float('nan')
-            nxt = (tr[b + 1] - tp[b]) / 100.0 if b + 1 < nb and tr[b + 1] else float('nan')
-            print(f"  b={b:2d} ready {rdy:9.1f} panel_done {(tp[b] - t0) / 100.0:9.1f} panel {(tp[b] - tr[b]) / 100.0 if b else float('nan'):8.1f} next_ready_after {nxt:8.1f}", flush=True)
+        t0 = min(x for x in tr if x)
+        print(f"n={n} {env}: {t:.2f} ms; column block complete [us]: " + " ".join(f"{(x - t0) / 100.0:.0f}" if x else "-" for x in tr), flush=True)

@@ -7,9 +7,14 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "build")
-LIB = os.path.join(HERE, "librflu.so")
-SOURCES = ["gemm.hip", "engine.hip", "panel.hip", "panel_f32.hip", "panel_local.hip", "panel_local_f32.hip", "panel_local_xcd.hip", "panel_local_xcd_f32.hip", "panel_single.hip", "panel_single_f32.hip", "panel_blocked.hip", "panel_blocked_f32.hip", "trsm.hip", "trsv.hip", "laswp.hip", "butterfly.hip", "driver.cpp"]
+OBJ = os.path.join(CSRC, "build_exp" if os.environ.get("RFLU_EXPERIMENTS", "0") not in ("", "0") else "build")
+LIB = os.path.join(HERE, "librflu_exp.so" if os.environ.get("RFLU_EXPERIMENTS", "0") not in ("", "0") else "librflu.so")
+# RFLU_EXPERIMENTS=1 in the environment of the BUILD adds the kernels that were measured and lost (the sub-panel
+# leaf of round 4) -- objects and library of their own (build_exp/, librflu_exp.so) so that the default build never contains them
+EXPERIMENTS = os.environ.get("RFLU_EXPERIMENTS", "0") not in ("", "0")
+SOURCES = ["gemm.hip", "engine.hip", "panel.hip", "panel_f32.hip", "panel_local.hip", "panel_local_f32.hip", "panel_local_xcd.hip", "panel_local_xcd_f32.hip", "panel_single.hip", "panel_single_f32.hip", "trsm.hip", "trsv.hip", "laswp.hip", "butterfly.hip", "driver.cpp"]
+if EXPERIMENTS:
+    SOURCES += ["panel_blocked.hip", "panel_blocked_f32.hip"]
 HEADERS = ["rflu_internal.hpp", os.path.join("..", "..", "include", "rflu.h")]   # included by every source
 ALL_HEADERS = HEADERS + ["panel_common.hpp", "panel_xchg.hpp", "trsm_row.hpp", "gemm_tile.hpp", "laswp_strip.hpp", "engine.hpp"]
 _PANEL_H = ["panel_common.hpp", "panel_xchg.hpp", "trsm_row.hpp"]
@@ -21,7 +26,7 @@ EXTRA_DEPS = {"gemm.hip": ["gemm_tile.hpp"], "engine.hip": ["gemm_tile.hpp", "la
               "panel_single_f32.hip": ["panel_single.hip", *_PANEL_H], "panel_blocked_f32.hip": ["panel_blocked.hip", *_PANEL_H]}
 # (a source that #includes another source, or a header only some sources see: kept per source so that touching one
 #  kernel family does not rebuild the others)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"] + (["-DRFLU_EXPERIMENTS"] if EXPERIMENTS else [])
 
 
 def _mtime(p):

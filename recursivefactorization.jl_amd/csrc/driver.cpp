@@ -105,7 +105,7 @@ void Tune::load_env()
     env_get("RFLU_ENGINE", engine);
     env_get("RFLU_ENGINE_POLICY", engine_policy);
     env_get("RFLU_ENGINE_WGS", engine_wgs);
-    env_get("RFLU_ENGINE_NOPANEL", engine_nopanel);
+    env_get("RFLU_ENGINE_ROWS", engine_rows);
     for (int i = 0; i < 8; ++i) {
         char name[32];
         snprintf(name, sizeof(name), "RFLU_ENGINE_X%d", i);
@@ -1254,7 +1254,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             // column 0, its side / update streams replaced by the engine); below that the streams and the XCD-local leaves take over
             int64_t eng_end = 0;
             if (leafwise && Wb >= 2 * NB && Wb <= 512 && W_wide == 0 && m <= 32 * (int64_t)PANEL_THREADS && engine_usable<T>(h, f, Wb)) {
-                const int64_t er = h->tune.engine_x[3] > 0 ? h->tune.engine_x[3] : 4096;   // RFLU_ENGINE_X3: panels taller than this go through the engine
+                const int64_t er = std::max<int64_t>(h->tune.engine_rows, 0);
                 eng_end = m <= er ? 0 : std::min(nblk, (m - er + Wb - 1) / Wb);
             }
             if (tail && b_switch == 0 && eng_end == 0) {

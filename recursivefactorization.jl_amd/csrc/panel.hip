@@ -517,6 +517,7 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
         h->epoch += (unsigned)NB;
     }
     ProfScope ps(h, RFLU_K_PANEL, (double)rows * (double)w * (double)w);
+#ifdef RFLU_EXPERIMENTS
     if (pivot && w == NB && panel_use_blocked(h, rows, sizeof(T))) {
         // the sub-panel kernel (panel_blocked.hip); XCD-local records for the short panels as below
         const int64_t local_rows = h->tune.panel_local_rows >= 0 ? h->tune.panel_local_rows : (sizeof(T) == 4 ? 8192 : 4096);
@@ -524,6 +525,7 @@ int launch_panel(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0,
         RFLU_TRY(launch_panel_blocked<T>(h, p, loc ? 1 : 0));
         return RFLU_OK;
     }
+#endif
     if (pivot && rows <= PANEL_THREADS && h->panel_single) {   // one workgroup, LDS only (panel_single.hip)
         RFLU_TRY(launch_panel_single<T>(h, p));
         return RFLU_OK;
@@ -591,21 +593,31 @@ template int launch_panel<double>(Handle*, double*, int64_t, int64_t, int64_t, i
 
 int panel_resident_limit(int num_cus)
 {
-    return std::min(std::min(std::min(panel_resident_limit_f64(num_cus), panel_resident_limit_f32(num_cus)),
-                             std::min(panel_local_resident_limit_f64(num_cus), panel_local_resident_limit_f32(num_cus))),
-                    std::min(panel_blocked_resident_limit_f64(num_cus), panel_blocked_resident_limit_f32(num_cus)));
+    int lim = std::min(std::min(panel_resident_limit_f64(num_cus), panel_resident_limit_f32(num_cus)),
+                       std::min(panel_local_resident_limit_f64(num_cus), panel_local_resident_limit_f32(num_cus)));
+#ifdef RFLU_EXPERIMENTS
+    lim = std::min(lim, std::min(panel_blocked_resident_limit_f64(num_cus), panel_blocked_resident_limit_f32(num_cus)));
+#endif
+    return lim;
 }
 
 // The sub-panel kernel takes a full pivoted leaf whenever it does not need a bigger CU reservation (a multiple of 32) than the
 // 512-row workgroups of the older leaves would: Float64 workgroups hold 448 rows, so panels of 14337..16384 rows (and 28673..32768)
 // stay with the older kernel -- the block columns of N = 16384 whose update, not whose panel, sets the pace.
+// (the sub-panel leaf is an experiment that measured no faster than the default leaves -- DESIGN.md section 9: it is compiled only
+//  into an RFLU_EXPERIMENTS build, `RFLU_EXPERIMENTS=1 python recursivefactorization.jl_amd/build.py`)
 bool panel_use_blocked(const Handle* h, int64_t rows, size_t esize)
 {
+#ifndef RFLU_EXPERIMENTS
+    (void)h; (void)rows; (void)esize;
+    return false;
+#else
     if (!h->panel_blocked || h->coop_launch) return false;
     const int64_t rpw = esize == 8 ? PANEL_BLOCKED_ROWS_F64 : PANEL_BLOCKED_ROWS_F32;
     const int64_t g = (rows + rpw - 1) / rpw, g_old = (rows + PANEL_THREADS - 1) / PANEL_THREADS;
     if (g > 64) return false;
     return (g + 31) / 32 <= (g_old + 31) / 32;
+#endif
 }
 
 int64_t panel_plan_wgs(const Handle* h, int64_t rows, size_t esize, int pivot)

@@ -108,12 +108,12 @@ struct Tune {
     // fault injection (tests): the cooperative leaf launch with this sequence number inside a factorization waits for a
     // participant that does not exist, runs into its bounded spin and raises the timeout flag (RFLU_ERR_TIMEOUT at the end)
     int debug_ghost_leaf = -1;         // RFLU_DEBUG_GHOST_LEAF
-    // persistent update engine (engine.hip)
-    int engine = 1;                    // RFLU_ENGINE: 1 = the trailing updates of the block-column schedule run in the persistent engine
-    int engine_policy = 0;             // RFLU_ENGINE_POLICY: 0 = oldest panel first, 1 = leftmost column block first
+    // persistent update engine (engine.hip): an experiment of round 5 -- correct, measured slower than the stream schedules
+    int engine = 0;                    // RFLU_ENGINE=1: the leaf-wise schedule's side / update stream work is pulled by the resident engine
+    int engine_policy = 0;             // RFLU_ENGINE_POLICY: 0 = leftmost column block first, 1 = oldest panel piece first
     int engine_wgs = 0;                // RFLU_ENGINE_WGS: resident workgroups (0: two per CU of the update mask)
-    int engine_x[8] = {};              // RFLU_ENGINE_X0..7: experiment switches of the engine (meaning in engine.hip / driver.cpp; 0 = default)
-    int engine_nopanel = 0;            // RFLU_ENGINE_NOPANEL=1: measurement only (wrong factors): no panels, every update eligible at once
+    int64_t engine_rows = 4096;        // RFLU_ENGINE_ROWS: block columns whose panels are taller than this go through the engine
+    int engine_x[8] = {};              // RFLU_ENGINE_X0..7: experiment switches (X0 = 1: no release fence, X1 = 1: no acquire -- timing only)
     void load_env();                   // driver.cpp
 };
 

@@ -60,14 +60,14 @@ if mode in ("quick", "all"):
     allok &= compare(6144, "f64", 512, m=10000)            # tall
     allok &= compare(10240, "f64", 512, m=6144)            # fat, m a multiple of W
     allok &= compare(8192, "f64", 0, {"RFLU_ENGINE_POLICY": "1"})
-    allok &= compare(8192, "f64", 0, {"RFLU_ENGINE_X3": "1024"})   # engine down to 1024-row panels
+    allok &= compare(8192, "f64", 0, {"RFLU_ENGINE_ROWS": "1024"})   # engine down to 1024-row panels
     allok &= compare(16384, "f64", 0)
     print("ALL OK" if allok else "FAILURES", flush=True)
 
 if mode in ("time", "all"):
     for n in (8192, 12288, 16384):
         for env in ({"RFLU_ENGINE": "0"}, {"RFLU_ENGINE": "1"}, {"RFLU_ENGINE": "1", "RFLU_ENGINE_POLICY": "1"},
-                    {"RFLU_ENGINE": "1", "RFLU_ENGINE_X3": "2048"}, {"RFLU_ENGINE": "1", "RFLU_ENGINE_X3": "6144"}):
+                    {"RFLU_ENGINE": "1", "RFLU_ENGINE_ROWS": "2048"}, {"RFLU_ENGINE": "1", "RFLU_ENGINE_ROWS": "6144"}):
             _, _, _, info, t = factor(n, "f64", 0, env, reps=4)
             print(f"n={n} {env}: info {info} best {t:.2f} ms", flush=True)
 

@@ -1,0 +1,66 @@
+"""-m gpu: the persistent update engine (csrc/engine.hip, RFLU_ENGINE=1 -- an experiment of round 5, off by default: DESIGN.md
+section 9).  Every trailing update of the block columns with tall panels is pulled by resident workgroups from per-column-block
+counters instead of being enqueued on the side / update streams; the eliminations and their order per column are those of the
+stream schedules (src/lu.jl:189-263, :265-284), so pivots must be identical and factors equal to rounding."""
+import numpy as np
+import pytest
+import torch
+
+import recursivefactorization.jl_amd as rf
+from gpu_util import fill_uniform_cm, matvec_residual
+
+pytestmark = pytest.mark.gpu
+
+
+def _factor(n, dtype, pivot, blocksize, m=None, diag_add=0.0):
+    A = fill_uniform_cm(n, dtype, 12, diag_add, m=m)
+    W = A.clone()
+    F = rf.lu_(W, None, pivot, check=False, blocksize=blocksize)
+    return A, F
+
+
+@pytest.mark.parametrize("m,n,bs,dtype", [
+    (6144, 6144, 256, np.float64),       # default width of this size: engine for the panels above 4096 rows, streams below
+    (8192, 8192, 512, np.float64),
+    (10000, 10000, 0, np.float64),       # last leaf partial
+    (10000, 6144, 512, np.float64),      # tall: every block column through the engine
+    (6144, 10240, 512, np.float64),      # fat (m a multiple of the block width)
+    (12288, 12288, 0, np.float64),
+])
+def test_engine_matches_stream_schedule(m, n, bs, dtype, monkeypatch):
+    monkeypatch.setenv("RFLU_ENGINE", "0")
+    A, F = _factor(n, dtype, True, bs, m=m)
+    monkeypatch.setenv("RFLU_ENGINE", "1")
+    for policy in ("0", "1"):
+        monkeypatch.setenv("RFLU_ENGINE_POLICY", policy)
+        _, G = _factor(n, dtype, True, bs, m=m)
+        assert F.info == G.info == 0
+        assert rf.last_path() == "hip-lookahead"
+        assert torch.equal(F.ipiv, G.ipiv)
+        scale = float(F.factors.abs().max())
+        assert float((F.factors - G.factors).abs().max()) <= 1e-10 * scale
+    if m == n:
+        assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
+
+
+def test_engine_nopivot_and_float32(monkeypatch):
+    monkeypatch.setenv("RFLU_ENGINE", "1")
+    n = 8192
+    A, F = _factor(n, np.float64, rf.NoPivot(), 0, diag_add=10.0)
+    assert F.info == 0
+    assert matvec_residual(A, F.factors, np.arange(1, n + 1)) < 10 * np.sqrt(20 * n * np.finfo(np.float64).eps)
+    # Float32: the pivot sequence may fork between two summation orders: info and the residual are pinned
+    A, F = _factor(n, np.float32, True, 0)
+    assert F.info == 0
+    assert matvec_residual(A, F.factors, F.ipiv) < 20 * n * np.finfo(np.float32).eps
+
+
+def test_engine_down_to_short_panels(monkeypatch):
+    """RFLU_ENGINE_ROWS lowers the hand-over to the streams: more leaves (and their K = 64 windows) go through the engine."""
+    monkeypatch.setenv("RFLU_ENGINE", "0")
+    A, F = _factor(6144, np.float64, True, 0)
+    monkeypatch.setenv("RFLU_ENGINE", "1")
+    monkeypatch.setenv("RFLU_ENGINE_ROWS", "1024")
+    _, G = _factor(6144, np.float64, True, 0)
+    assert torch.equal(F.ipiv, G.ipiv)
+    assert matvec_residual(A, G.factors, G.ipiv) < 1e-12

@@ -70,6 +70,7 @@ void Tune::load_env()
     env_get("RFLU_LD_PAD", ld_pad);
     ld_pad = (ld_pad / 16) * 16;
     env_get("RFLU_TRSV_MAX_RHS", trsv_max_rhs);
+    env_get("RFLU_TRSM_CHAIN_MAX_RHS", trsm_chain_max_rhs);
     env_get("RFLU_QUEUE_CHECK", queue_check);
     env_flag("RFLU_QUEUE_TRACE", queue_trace);
     env_flag("RFLU_SPLIT_ALL", split_all);
@@ -234,9 +235,12 @@ static int getrs_rm(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, 
     // instead of ~n/32 dependent launches; many:
     // the recursive splitting, whose GEMMs then carry the work.  RFLU_TRSV_MAX_RHS moves the crossover (0 = never).
     const int64_t trsv_max = h->tune.trsv_max_rhs;
-    if (nrhs <= trsv_max && n <= (int64_t)NB * 256 * 4) {
+    // a block of right-hand sides (33 .. trsm_chain_max_rhs): the same cooperative chain in passes of 64 columns on the MFMA units
+    // (trsv.hip: trsm_chain_kernel; n = 16384, 64 right-hand sides: 28.8 ms with the recursive splitting below)
+    const bool wide = nrhs > trsv_max && nrhs <= h->tune.trsm_chain_max_rhs;
+    if ((nrhs <= trsv_max || wide) && n <= (int64_t)NB * 256 * 4) {
         RFLU_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int64_t), h->stream));
-        RFLU_TRY(launch_trsv_coop<T>(h, n, nrhs, R, ld, B, ldb));
+        RFLU_TRY(launch_trsv_coop<T>(h, n, nrhs, R, ld, B, ldb, wide));
         RFLU_HIP(hipMemcpyAsync(h->info_pinned, h->info_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
         RFLU_HIP(hipStreamSynchronize(h->stream));
         if (h->info_pinned[1] != 0) {

@@ -71,6 +71,7 @@ struct Tune {
     int gemm_masked = -1;              // RFLU_GEMM_MASKED: stand-alone rflu_gemm_* calls on the CU-masked stream leaving this many CUs free
     int64_t ld_pad = 0;                // RFLU_LD_PAD
     int64_t trsv_max_rhs = 32;         // RFLU_TRSV_MAX_RHS
+    int64_t trsm_chain_max_rhs = 320;  // RFLU_TRSM_CHAIN_MAX_RHS: up to this many right-hand sides the cooperative solve in passes of 64 (MFMA)
     // streams and queues
     int queue_check = 1;               // RFLU_QUEUE_CHECK
     int queue_trace = 0;               // RFLU_QUEUE_TRACE
@@ -289,7 +290,7 @@ template <typename T>
 int launch_trsm_inv64(Handle* h, int64_t n, int64_t nrhs, const T* Linv, T* B, int64_t ldb);   // one block, LDS-free
 // cooperative solve for few right-hand sides (trsv.hip): B <- U^-1 L^-1 B, interchanges already applied
 template <typename T>
-int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, T* B, int64_t ldb);
+int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, T* B, int64_t ldb, bool wide = false);
 // stream gates folded into an interchange launch (laswp.hip; used by factor_leafwise): hold the launch until *wait_flag >=
 // wait_val, and let its last workgroup publish signal_val (signal_cnt: a zero-initialised counter that wraps by itself)
 struct LaswpGate {

@@ -346,6 +346,284 @@ __global__ void __launch_bounds__(TV_THREADS) trsv_chain_kernel(int n, int nrhs,
     }
 }
 
+// =====================================================================================================================
+// The same solve for a BLOCK of right-hand sides (33 .. a few hundred; round 5): 64 columns per pass, the block products on the
+// MFMA units.  With the recursive splitting (driver.cpp: trsm_rec / triu_solve_rec) 64 right-hand sides at n = 16384 were ~1000
+// dependent launches of almost no work: 28.8 ms, fifteen times the one-right-hand-side solve, for the same 2 GiB of factor bytes.
+// Here the chain of trsv_chain_kernel carries 64 columns at once:
+//   * block r of the right-hand sides (64 x 64) belongs to workgroup r mod G and stays in B (global memory; this workgroup is the
+//     only one that touches it until it is solved);
+//   * stage d: x_d arrives as tagged granules (or from this workgroup's own LDS copy), every workgroup subtracts T_rd * x_d from the
+//     blocks it owns further on -- 64 MFMAs per wave, the A operand straight from the factor (each 64 x 64 block of the triangle is
+//     read exactly once), the B operand x_d from LDS, the C tile read from / written to B;
+//   * the chain per stage is ONE product: the owner of the next block holds y = inv(D) (b - everything but the last stage),
+//     prepared while x_d was still on its way, and M = inv(D) T (trsv_sub_kernel): x_next = y - M x_d, published at once.
+// Wave w owns rows [16w, 16w+16) of a 64-row block x 64 columns = 4 accumulator fragments.
+// Measured (n = 16384, 64 right-hand sides, stamps of the owner of the next block): 9.7 us per stage = 2.1 us for the product (64
+// v_mfma_f64_16x16x4 of 64 clocks each per wave) + ~5 us from the previous owner's first granule store to x_d in this workgroup's LDS
+// (64 KB of granules through the memory side) + the owner's own previous stage (its block's update and y: two more products).
+constexpr int TC_NR = 64;                 // right-hand sides per pass
+constexpr int TC_XLD = TC_NR + 16;        // LDS row pitch of x_d ([k][column]; == 16 mod 32 doubles: conflict-free fragment reads)
+
+template <typename T>
+struct TcMfma;
+template <>
+struct TcMfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct TcMfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+// A fragments of a 64 x 64 block M (row-major, leading dimension ldm; rows >= rows_ok / columns >= cols_ok read as zero):
+// lane (fi = lane & 15, fk = lane >> 4) of wave w holds M[16w + fi][4 kk + fk], kk = 0..15
+template <typename T>
+__device__ __forceinline__ void tc_load_a(const T* __restrict__ M, int64_t ldm, int rows_ok, int cols_ok, int wave, int lane, T (&a)[16], bool neg)
+{
+    const int fi = lane & 15, fk = lane >> 4;
+    const int row = wave * 16 + fi;
+    const T* Mp = M + (int64_t)row * ldm + fk;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const T v = (row < rows_ok && 4 * kk + fk < cols_ok) ? Mp[4 * kk] : T(0);
+        a[kk] = neg ? -v : v;
+    }
+}
+
+// acc += A * xs   (xs: [64][TC_XLD] in LDS)
+template <typename T>
+__device__ __forceinline__ void tc_mma(const T (&a)[16], const T* xs, int lane, typename TcMfma<T>::acc_t (&acc)[4])
+{
+    const int fi = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const T* xr = xs + (4 * kk + fk) * TC_XLD + fi;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = TcMfma<T>::run(a[kk], xr[16 * t], acc[t]);
+    }
+}
+
+template <typename T, bool UPPER>
+__global__ void __launch_bounds__(TV_THREADS) trsm_chain_kernel(int n, int nrhs, const T* __restrict__ R, int64_t ld,
+                                                                const T* __restrict__ Dinv, const T* __restrict__ Msub, T* X, int64_t ldx,
+                                                                void* xchg, unsigned xchg_bytes, unsigned tag, int64_t* err)
+{
+    typedef typename TcMfma<T>::acc_t acc_t;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xchg, 0, xchg_bytes, 0x00020000);
+    __shared__ T xs[2][NB * TC_XLD];   // x_d by parity of the stage
+    __shared__ T ys[NB * TC_XLD];      // the block two stages ahead, staged as a B operand for y = inv(D) * b
+    __shared__ int s_dead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15;
+    const int nb = (n + NB - 1) / NB;
+    const int G = gridDim.x, w = blockIdx.x;
+    const int dir = UPPER ? -1 : 1;
+    const int d0 = UPPER ? nb - 1 : 0;
+    if (tid == 0) s_dead = 0;
+    auto rows_of = [&](int r) { return min(NB, n - r * NB); };
+    // C-layout access to block r of X: row 16w + crow(lane, q), column 16t + fi
+    auto load_c = [&](int r, acc_t (&c)[4]) {
+        const int rn = rows_of(r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave * 16 + TcMfma<T>::crow(lane, q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int col = 16 * t + fi;
+                c[t][q] = (row < rn && col < nrhs) ? X[(int64_t)(r * NB + row) * ldx + col] : T(0);
+            }
+        }
+    };
+    auto store_c = [&](int r, const acc_t (&c)[4]) {
+        const int rn = rows_of(r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave * 16 + TcMfma<T>::crow(lane, q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int col = 16 * t + fi;
+                if (row < rn && col < nrhs) X[(int64_t)(r * NB + row) * ldx + col] = c[t][q];
+            }
+        }
+    };
+    auto stage_c = [&](T* dst, const acc_t (&c)[4]) {   // C layout -> [row][TC_XLD] in LDS
+        // (volatile: one ds_write per element.  hipcc 7.2 paired the Float32 writes of this loop into ds_write2_b32 with a wrong first
+        //  offset -- column 4 instead of 16 for the second fragment -- and a quarter of the staged block kept its old contents)
+        volatile T* vd = dst;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave * 16 + TcMfma<T>::crow(lane, q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vd[row * TC_XLD + 16 * t + fi] = c[t][q];
+        }
+    };
+    // x_r = c: granules for the other workgroups, the final values into X, and this workgroup's own copy for the stage that uses it
+    auto publish = [&](int r, const acc_t (&c)[4], T* own) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave * 16 + TcMfma<T>::crow(lane, q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                tv_store(rx, (unsigned)((r * NB + row) * TC_NR + 16 * t + fi) * 16u, tag, c[t][q]);
+        }
+        stage_c(own, c);
+        store_c(r, c);
+    };
+    auto owner_of = [&](int r) { return r % G; };
+    // next owned block at or beyond block r in solve order (-1: none)
+    auto owned_from = [&](int r) -> int {
+        if (!UPPER) {
+            if (r >= nb) return -1;
+            const int q = r + ((w - r) % G + G) % G;
+            return q < nb ? q : -1;
+        }
+        if (r < 0) return -1;
+        const int q = r - ((r - w) % G + G) % G;
+        return q >= 0 ? q : -1;
+    };
+    int ns = owned_from(d0);             // the block this workgroup solves next
+    const bool single = nb <= G;         // one block per workgroup: it stays in registers from the first stage to its solution
+    acc_t yv[4];                         // y of that block (valid from the stage before it is solved)
+    acc_t cacc[4];                       // single: the block itself, minus everything subtracted so far
+#pragma unroll
+    for (int t = 0; t < 4; ++t) yv[t] = cacc[t] = acc_t{T(0), T(0), T(0), T(0)};
+    T mcrit[16], dcrit[16];              // A fragments of -M_ns and of inv(D_ns): requested when ns changes, a stage or more ahead of their use
+    auto load_crit = [&]() {
+        if (ns >= 0) {
+            tc_load_a<T>(Msub + (size_t)ns * NB * NB, NB, NB, NB, wave, lane, mcrit, true);
+            tc_load_a<T>(Dinv + (size_t)ns * NB * NB, NB, NB, NB, wave, lane, dcrit, false);
+        }
+    };
+    load_crit();
+    __syncthreads();
+    // y = inv(D_r) * b_r with b_r read from X through the LDS staging (b_r is complete but for the stage that uses M)
+    auto make_y = [&](int r, const T (&dv)[16], acc_t (&y)[4]) {
+        acc_t c[4];
+        load_c(r, c);
+        stage_c(ys, c);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y[t] = acc_t{T(0), T(0), T(0), T(0)};
+        tc_mma<T>(dv, ys, lane, y);
+        __syncthreads();   // ys may be rewritten
+    };
+    // prologue: the first block is solved outright, the second one has its y before the first stage
+    if (ns == d0) {
+        acc_t x0[4];
+        make_y(d0, dcrit, x0);
+        publish(d0, x0, xs[0]);
+        ns = owned_from(d0 + dir * G);
+        load_crit();
+    }
+    if (ns == d0 + dir) make_y(ns, dcrit, yv);
+    else if (single && ns >= 0) load_c(ns, cacc);
+    // -T of the first stage's nearest trailing block (requested a stage ahead from here on)
+    T tnear[16];
+    {
+        const int rn = owned_from(d0 + 2 * dir);
+        if (rn >= 0) tc_load_a<T>(R + (int64_t)rn * NB * ld + d0 * NB, ld, rows_of(rn), min(NB, n - d0 * NB), wave, lane, tnear, true);
+    }
+    __syncthreads();
+
+    for (int s = 0; s + 1 < nb; ++s) {   // the last block's x has nobody to go to
+        const int d = d0 + dir * s, dnext = d + dir;
+        T* xd = xs[s & 1];
+        if (owned_from(dnext) < 0) break;   // nothing left for this workgroup (workgroup-uniform)
+        // ---- x_d
+        if (w != owner_of(d)) {
+            const bool urgent = ns == dnext || ns == dnext + dir;
+            // thread -> row k = tid >> 2, columns (tid & 3) * 16 + j: all 16 granules requested, the missing ones again
+            const int k = tid >> 2, cb = (tid & 3) * 16;
+            T v[16];
+            unsigned miss = 0xffffu;
+            int spins = 0;
+            bool timed_out = false;
+            const unsigned goff = (unsigned)((d * NB + k) * TC_NR + cb) * 16u;
+            if (!urgent) {
+                // a workgroup whose turn is not near waits for ONE granule of x_d with one lane, at leisure, and fetches the block
+                // when that one is there: 250 workgroups sweeping 64 KB per poll round took the fabric from the two that matter
+                // (10 us per stage instead of 5)
+                if (tid == 0) {
+                    T probe;
+                    while (!tv_load(rx, (unsigned)((d * NB + NB - 1) * TC_NR + TC_NR - 1) * 16u, tag, probe)) {
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_s_sleep(32);
+                        if (++spins > TV_SPIN_LIMIT / 8) break;   // (the sweep below times out properly)
+                    }
+                }
+                spins = 0;
+                __syncthreads();
+            }
+            while (miss) {
+                asm volatile("" ::: "memory");
+                // all sixteen requests in flight before the first tag is looked at (a test between two loads makes them sixteen
+                // dependent round trips: 12 us per stage instead of 5)
+                bool okj[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) okj[j] = tv_load(rx, goff + (unsigned)j * 16u, tag, v[j]);
+                miss = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) miss |= okj[j] ? 0u : (1u << j);
+                if (miss) {
+                    if (!urgent) __builtin_amdgcn_s_sleep(8);
+                    if (++spins > TV_SPIN_LIMIT) { timed_out = true; break; }
+                }
+            }
+            volatile T* vx = xd;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vx[k * TC_XLD + cb + j] = v[j];
+            if (timed_out) {
+                s_dead = 1;
+                __hip_atomic_store((unsigned long long*)(err + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (s_dead) return;
+        // ---- the chain: the next block is this workgroup's.  x_next = y + (-M) x_d: the accumulators start from y
+        if (ns == dnext) {
+            acc_t mx[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mx[t] = yv[t];
+            tc_mma<T>(mcrit, xd, lane, mx);
+            publish(ns, mx, xs[(s + 1) & 1]);
+            ns = owned_from(ns + dir * G);
+            load_crit();
+            if (single) break;   // (its only block is solved)
+        }
+        // ---- T_rd x_d off the blocks owned further on, the nearest first (its -T came a stage ago)
+        bool first = true;
+        for (int r = owned_from(dnext + dir); r >= 0; r = owned_from(r + dir * G)) {
+            if (!first) tc_load_a<T>(R + (int64_t)r * NB * ld + d * NB, ld, rows_of(r), min(NB, n - d * NB), wave, lane, tnear, true);
+            first = false;
+            if (single) {
+                tc_mma<T>(tnear, xd, lane, cacc);
+            } else {
+                load_c(r, cacc);
+                tc_mma<T>(tnear, xd, lane, cacc);
+                store_c(r, cacc);
+            }
+            if (r == dnext + dir && r == ns) {
+                // the block after next is this workgroup's: everything but x_next has reached it -- its y (the tile is in registers)
+                stage_c(ys, cacc);
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) yv[t] = acc_t{T(0), T(0), T(0), T(0)};
+                tc_mma<T>(dcrit, ys, lane, yv);
+            }
+        }
+        if (s + 2 < nb) {   // -T of the next stage's nearest trailing block
+            const int rn = owned_from(dnext + 2 * dir);
+            if (rn >= 0) tc_load_a<T>(R + (int64_t)rn * NB * ld + dnext * NB, ld, rows_of(rn), min(NB, n - dnext * NB), wave, lane, tnear, true);
+        }
+        __syncthreads();  // everybody is done with xs[s & 1] / ys before the stage after next rewrites them
+    }
+}
+
 template <typename T, int NR>
 static int launch_trsv_pass(Handle* h, unsigned grid, int64_t n, int nr, const T* R, int64_t ld, const T* Linv, const T* Uinv, const T* Lsub,
                             const T* Usub, T* B, int64_t ldb, void* xchg, size_t xchg_bytes)
@@ -360,15 +638,16 @@ static int launch_trsv_pass(Handle* h, unsigned grid, int64_t n, int nr, const T
 }
 
 // B <- U^-1 L^-1 B for nrhs <= TV_NR per pass (row-major factors R, row-major B); interchanges already applied to B.
+// wide: passes of TC_NR = 64 right-hand sides on the MFMA units (trsm_chain_kernel) instead of TV_NR = 8 on the vector units.
 template <typename T>
-int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, T* B, int64_t ldb)
+int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld, T* B, int64_t ldb, bool wide)
 {
     if (n <= 0 || nrhs <= 0) return RFLU_OK;
     const int64_t nb = (n + NB - 1) / NB;
     // workspace: inverted diagonal blocks of L and of U, their products with the blocks next to the diagonal, then the exchange
     // area (one 16-byte granule per value of x)
     const size_t inv_bytes = (size_t)nb * NB * NB * sizeof(T);
-    const size_t xchg_bytes = (size_t)nb * NB * TV_NR * 16;
+    const size_t xchg_bytes = (size_t)nb * NB * (wide ? TC_NR : TV_NR) * 16;
     const size_t need = 4 * inv_bytes + xchg_bytes;
     const bool fresh = need > h->linv_tmp_bytes;
     RFLU_TRY(ensure_buffer(&h->linv_tmp, &h->linv_tmp_bytes, need));
@@ -405,12 +684,30 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
                 (void)hipGetLastError();
                 a = b = 0;
             }
-            h->trsv_max_wgs = std::max(1, std::min(a, b) * h->num_cus);
+            int c = 0, d = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&trsm_chain_kernel<T, false>), TV_THREADS, 0) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, reinterpret_cast<const void*>(&trsm_chain_kernel<T, true>), TV_THREADS, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                c = d = 0;
+            }
+            h->trsv_max_wgs = std::max(1, std::min(std::min(a, b), std::min(c, d)) * h->num_cus);
         }
         if ((int)grid > h->trsv_max_wgs) {
             set_error("launch_trsv_coop: %u cooperating workgroups, but the device holds %d at a time", grid, h->trsv_max_wgs);
             return RFLU_ERR_ARG;
         }
+    }
+    if (wide) {
+        for (int64_t c0 = 0; c0 < nrhs; c0 += TC_NR) {
+            const int nr = (int)std::min<int64_t>(TC_NR, nrhs - c0);
+            ProfScope ps(h, RFLU_K_TRSM, 2.0 * (double)n * (double)n * (double)nr, sizeof(T) * (double)n * (double)n);
+            hipLaunchKernelGGL((trsm_chain_kernel<T, false>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Linv, Lsub, B + c0, ldb,
+                               xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev);
+            hipLaunchKernelGGL((trsm_chain_kernel<T, true>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Uinv, Usub, B + c0, ldb,
+                               xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev);
+            RFLU_HIP(hipGetLastError());
+        }
+        return RFLU_OK;
     }
     for (int64_t c0 = 0; c0 < nrhs; c0 += TV_NR) {
         const int nr = (int)std::min<int64_t>(TV_NR, nrhs - c0);
@@ -420,7 +717,7 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
     return RFLU_OK;
 }
 
-template int launch_trsv_coop<double>(Handle*, int64_t, int64_t, const double*, int64_t, double*, int64_t);
-template int launch_trsv_coop<float>(Handle*, int64_t, int64_t, const float*, int64_t, float*, int64_t);
+template int launch_trsv_coop<double>(Handle*, int64_t, int64_t, const double*, int64_t, double*, int64_t, bool);
+template int launch_trsv_coop<float>(Handle*, int64_t, int64_t, const float*, int64_t, float*, int64_t, bool);
 
 }  // namespace rflu

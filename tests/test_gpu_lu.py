@@ -174,6 +174,22 @@ def test_lookahead_schedules_tall_panels_and_split(shape, blocksize, env, monkey
     check_against_oracle(A, F)
 
 
+def test_wilkinson_single_leaf_exact_growth():
+    # n <= 64: one leaf, no inverse products anywhere -- the growth 2^(k-1) is exact (test/runtests.jl:130-140)
+    for n in (17, 64):
+        W = wilkinson(n)
+        G = rf.lu(W, True, check=False, blocksize=-1)
+        assert G.info == 0 and np.array_equal(G.ipiv, np.arange(1, n + 1))
+        assert np.array_equal(np.asarray(G.factors)[:, -1], 2.0 ** np.arange(n))
+
+
+@pytest.mark.parametrize("shape,bs", [((1000, 1000), 0), ((2048, 2048), 512), ((700, 384), 0), ((300, 900), 0)])
+def test_more_geometries_against_oracle(shape, bs):
+    A = rand_matrix(shape[0], shape[1], seed=77)
+    F = rf.lu(A, True, check=False, blocksize=bs)
+    check_against_oracle(A, F)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_wilkinson_all_ties_exact_growth(dtype):
     # all-ties pivoting (test/runtests.jl:130-140): identity pivots, exact growth 2^(k-1) (Float32 stays finite up to 2^127)
@@ -187,9 +203,11 @@ def test_wilkinson_all_ties_exact_growth(dtype):
     assert np.allclose(np.asarray(G.factors)[:, -1], want, rtol=8 * np.finfo(dtype).eps, atol=0)
 
 
-@pytest.mark.parametrize("n,nrhs", [(129, 8), (1000, 9), (3000, 1), (3000, 20), (4100, 64), (2000, 70), (5000, 5)])
+@pytest.mark.parametrize("n,nrhs", [(129, 8), (1000, 9), (3000, 1), (3000, 20), (4100, 64), (2000, 70), (5000, 5), (1000, 33),
+                                    (2100, 130), (300, 64), (4100, 400)])
 def test_ldiv_cooperative_and_recursive_paths(n, nrhs):
-    # up to 64 right-hand sides: one cooperative launch per triangle and pass of 8 (trsv.hip); beyond: recursive TRSM/GEMM.
+    # up to 32 right-hand sides: one cooperative launch per triangle and pass of 8 (trsv.hip: trsv_chain_kernel); 33 .. 320: the same
+    # chain in passes of 64 columns on the MFMA units (trsm_chain_kernel, round 5); beyond: recursive TRSM/GEMM.
     # Same bound as runtests.jl:126-128, on a general (pivoted) matrix and through the device entry
     A = rand_matrix(n, n, seed=900 + n)
     B = rand_matrix(n, nrhs, seed=901 + n).copy(order="F")
@@ -201,6 +219,23 @@ def test_ldiv_cooperative_and_recursive_paths(n, nrhs):
     scale = np.linalg.norm(A, 2) * np.linalg.norm(Xref) + np.linalg.norm(B)
     assert np.linalg.norm(A @ X - B) < 1000 * n * np.finfo(np.float64).eps * scale
     assert np.linalg.norm(X - Xref) / np.linalg.norm(Xref) < 1e-6   # cond(rand(n,n)) ~ n: far above what we need
+
+
+@pytest.mark.parametrize("dtype,n,nrhs", [(np.float64, 1500, 64), (np.float64, 1500, 100), (np.float32, 1500, 64), (np.float32, 700, 200)])
+def test_ldiv_block_of_right_hand_sides_matches_recursive_path(dtype, n, nrhs, monkeypatch):
+    """ldiv!(F, B) with a block of right-hand sides (src/lu.jl:60-64, test/runtests.jl:116-128): the cooperative MFMA chain
+    (RFLU_TRSM_CHAIN_MAX_RHS, default 320) against the recursive TRSM/GEMM splitting it replaces for 33 .. 320 columns -- same
+    factors, same interchanges: solutions equal to rounding, residual inside the reference's bound."""
+    eps = np.finfo(dtype).eps
+    D = (rand_matrix(n, n, seed=610 + n, dtype=dtype) + dtype(10) * np.eye(n, dtype=dtype)).astype(dtype, order="F")
+    B = rand_matrix(n, nrhs, seed=611 + n, dtype=dtype).copy(order="F")
+    F = rf.lu_(to_dev_cm(D), None, True)
+    X = to_dev_cm(B); rf.ldiv_(F, X)
+    monkeypatch.setenv("RFLU_TRSM_CHAIN_MAX_RHS", "0")
+    Y = to_dev_cm(B); rf.ldiv_(F, Y)
+    x, y = X.cpu().numpy().astype(np.float64), Y.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(D.astype(np.float64) @ x - B) < 1000 * n * eps * np.sqrt(nrhs)
+    assert np.linalg.norm(x - y) <= 100 * eps * np.linalg.norm(y)
 
 
 def test_row_major_device_entry():

@@ -80,10 +80,6 @@ int rflu_debug_heat(rflu_handle_t handle, double usec);
 /* Measurement aid (scripts/gate_trace.py): with RFLU_GATE_TRACE=1 in the environment the leaf-wise schedule stamps the wall
  * clock (100 MHz ticks) when each stream passes each leaf; copies the 3 x 4096 stamps to `out` (host). */
 int rflu_debug_gate_stamps(rflu_handle_t handle, long long* out);
-/* Measurement aid (scripts/engine_check.py): per block column of the last factorization that went through the persistent update
- * engine, the wall clock (100 MHz ticks) at which the column block had received every update and at which its panel was
- * published to the engine; n entries each (host). */
-int rflu_debug_engine_times(rflu_handle_t handle, long long* t_ready, long long* t_panel, int n);
 
 /* ---- the boundary: lu!(A, ipiv, pivot; blocksize) on HOST buffers (caller-owned, column-major) ----
  * Replaces src/lu.jl:114-126 (recursive path + unblocked fallback) for Float64 / Float32.

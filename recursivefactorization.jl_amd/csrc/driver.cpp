@@ -22,6 +22,7 @@
 
 #include "rflu_internal.hpp"
 #include "engine.hpp"
+#include <atomic>
 #include <chrono>
 #include <thread>
 
@@ -107,6 +108,7 @@ void Tune::load_env()
     env_get("RFLU_ENGINE_POLICY", engine_policy);
     env_get("RFLU_ENGINE_WGS", engine_wgs);
     env_get("RFLU_ENGINE_ROWS", engine_rows);
+    env_get("RFLU_ENGINE_HOST", engine_host);
     for (int i = 0; i < 8; ++i) {
         char name[32];
         snprintf(name, sizeof(name), "RFLU_ENGINE_X%d", i);
@@ -835,7 +837,7 @@ template <typename T>
 static int engine_usable(const Handle* h, const Fact<T>& f, int64_t W)
 {
     constexpr int64_t VW = 16 / (int64_t)sizeof(T);
-    return h->tune.engine != 0 && W % 128 == 0 && f.roff == 0 && reinterpret_cast<uintptr_t>(f.R) % 16 == 0 && f.ld % VW == 0 &&
+    return (h->tune.engine != 0 || h->eng_host_mode) && W % 128 == 0 && f.roff == 0 && reinterpret_cast<uintptr_t>(f.R) % 16 == 0 && f.ld % VW == 0 &&
            f.m < (int64_t)1 << 30 && f.n < (int64_t)1 << 30 && (f.n + W - 1) / W <= ENG_MAX_CB && !h->progress && !h->mask_failed &&
            !h->tune.schedule_events && h->num_cus == 256 &&
            (f.m >= f.n || f.m % W == 0);   // (a fat matrix whose last panel ends inside a column block: the columns right of it in that block)
@@ -977,6 +979,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         geo.m = (int)m; geo.n = (int)n; geo.mn = (int)mn; geo.W = (int)W; geo.nbp = (int)eng_end; geo.ncb = (int)((n + W - 1) / W);
         geo.pivot = f.pivot;
         const size_t bytes = offsetof(EngState, cb) + (size_t)geo.ncb * sizeof(EngCB);
+        const size_t skip = offsetof(EngState, remaining);   // (the arrival word in front belongs to the feeding stream: getrf_host_engine)
         memset(img, 0, bytes);
         for (int cb = 0; cb < geo.ncb; ++cb) {
             EngCB& c = img->cb[cb];
@@ -994,14 +997,19 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             img->remaining += lk < nleft;
         }
         // the initial state travels on the caller's stream, in front of everything the engine is going to wait for
-        RFLU_HIP(hipMemcpyAsync(est, img, bytes, hipMemcpyHostToDevice, P));
+        RFLU_HIP(hipMemcpyAsync(reinterpret_cast<char*>(est) + skip, reinterpret_cast<char*>(img) + skip, bytes - skip, hipMemcpyHostToDevice, P));
         RFLU_TRY(record_on(P, EX + (size_t)nblk + 1));
         RFLU_TRY(wait_on(E, EX + (size_t)nblk + 1));
         EngArgs<T> a;
         a.R = R; a.ld = ld; a.g = geo; a.policy = h->tune.engine_policy;
         a.linv = static_cast<const T*>(h->linv); a.pm_cnt = h->pm_cnt; a.pm_dst = h->pm_dst; a.pm_src = h->pm_src;
         a.st = est; a.leaf_gate = h->gate_ptr[0]; a.gate_base = gbase; a.info = h->info_dev; a.gemm_flags = h->tune.gemm_flags;
+        a.arrived = h->eng_host_mode ? &est->arrived : nullptr;
+        a.rows_final = h->eng_host_mode ? h->eng_rows_final_dev : nullptr;
         for (int i = 0; i < 8; ++i) a.x[i] = h->tune.engine_x[i];
+        // host entry: whole-block-column operations that lag the chain by this many block columns go first (engine.hip), so that
+        // block rows become final -- and leave -- while the factorization runs (N=16384: 3: 123 ms, 5: 109-110, 8: 112, none: 118)
+        if (h->eng_host_mode && a.x[3] == 0) a.x[3] = 5;
         const int wgs = h->tune.engine_wgs > 0 ? h->tune.engine_wgs : 2 * (h->num_cus - 32);
         if (img->remaining > 0) RFLU_TRY(launch_engine<T>(h, E, a, wgs));
         RFLU_TRY(record_on(E, evUend(eng_end - 1)));   // the engine leaves when every column block has received everything it owes
@@ -1038,6 +1046,8 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             }
         }
         const int64_t g0 = j0 / NB, nl = (jb + NB - 1) / NB;
+        if (in_eng && h->eng_host_mode)   // host entry: the block column (and the lookahead strip of its last leaf) has to be in place
+            RFLU_TRY(launch_eng_wait(h, &est->arrived, (unsigned long long)std::min<int64_t>(n, je + NB)));
         for (int64_t i = 0; i < nl; ++i) {
             const int64_t g = g0 + i, c0 = j0 + i * NB, w = std::min<int64_t>(NB, je - c0);
             RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, f.ipiv, f.pivot));
@@ -1258,8 +1268,12 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             // column 0, its side / update streams replaced by the engine); below that the streams and the XCD-local leaves take over
             int64_t eng_end = 0;
             if (leafwise && Wb >= 2 * NB && Wb <= 512 && W_wide == 0 && m <= 32 * (int64_t)PANEL_THREADS && engine_usable<T>(h, f, Wb)) {
-                const int64_t er = std::max<int64_t>(h->tune.engine_rows, 0);
+                const int64_t er = h->eng_host_mode ? 0 : std::max<int64_t>(h->tune.engine_rows, 0);   // (host entry: every block column through the engine)
                 eng_end = m <= er ? 0 : std::min(nblk, (m - er + Wb - 1) / Wb);
+            }
+            if (h->eng_host_mode && eng_end < nblk) {   // the caller feeds the matrix in behind our back: only the engine waits for it
+                set_error("getrf: host entry through the engine asked for a schedule the engine cannot serve");
+                return RFLU_ERR_ARG;
             }
             if (tail && b_switch == 0 && eng_end == 0) {
                 RFLU_HIP(hipStreamWaitEvent(h->stream, tail, 0));
@@ -1360,6 +1374,212 @@ static int getrf_cm_dev(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int6
     return RFLU_OK;
 }
 
+// ---- host entry through the update engine: the way in overlaps the factorization (round 5) -----------------------------------------
+// The reference's boundary is a host array (src/lu.jl:116-121).  Round 3 overlapped the way BACK with the factorization; the way in
+// (38 ms of PCIe for a 16384^2 Float64 matrix) still preceded everything, because the stream schedules' first update touches every
+// column.  The engine's per-column-block dataflow does not: a column block's operations become eligible when its columns have
+// arrived, so the matrix is fed in block column by block column (a second host thread: copies from pageable memory block their
+// caller) -- copy, layout change, a word that says how many columns are in place -- while the critical-path stream, which waits on the
+// same word, factors what is there; finished block rows leave as before, told by a host-visible word the engine keeps
+// (EngArgs::rows_final) instead of events.  Every block column goes through the engine here (no hand-over to the streams).
+// *handled = false: not a case for this path (the caller falls back to getrf_host's sequence), nothing has been touched.
+template <typename T>
+static int getrf_host_engine(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv, int pivot, int64_t blocksize,
+                             int64_t* info, bool* handled)
+{
+    *handled = false;
+    const int64_t mn = std::min(m, n);
+    const int64_t chunk = h->tune.host_early_out;
+    const int64_t W = round_up(blocksize == 0 ? default_blocksize(mn) : blocksize, NB);
+    // Float64 with pivoting only: the engine applies the same eliminations in another summation order than the stream schedules, which
+    // a Float32 pivot search may answer with another (equally valid) pivot sequence and an unpivoted factorization with visibly other
+    // digits -- those keep the stream path, whose host entry is bit-identical to the device entry
+    if (sizeof(T) != 8 || !pivot) return RFLU_OK;
+    if (!h->tune.engine_host || h->prof || h->prof_one_stream || h->num_cus != 256 || !h->tune.leafwise || h->tune.schedule_events ||
+        chunk < 64 || mn < 8192 || m > 32 * (int64_t)PANEL_THREADS || m < n || W < 2 * NB || W > 512 || W % 128 != 0 || W >= mn ||
+        (blocksize == 0 && mn >= 20480))
+        return RFLU_OK;
+    const int64_t ldr = workspace_ld(h, n);
+    hipStream_t E, IN, OUT;
+    RFLU_TRY(get_ustream(h, 32, &E));
+    RFLU_TRY(get_ustream(h, 64, &E));    // (what getrf_rm creates before it settles the queues: nothing new appears afterwards)
+    RFLU_TRY(get_pstream(h, 32, &IN));   // streams confined to the CUs the resident engine leaves free: anything else would wait for it
+    RFLU_TRY(get_pstream(h, 64, &OUT));
+    if (h->mask_failed) return RFLU_OK;
+    RFLU_TRY(validate_queues(h));
+    RFLU_TRY(get_pstream(h, 32, &IN));
+    RFLU_TRY(get_pstream(h, 64, &OUT));
+    // buffers: device copy of the input (kept intact for a failed call), row-major workspace, staging + pinned bounce buffers of the way back
+    RFLU_TRY(ensure_buffer(&h->hostA_dev, &h->hostA_bytes, (size_t)m * (size_t)n * sizeof(T)));
+    RFLU_TRY(ensure_buffer(&h->work, &h->work_bytes, (size_t)m * (size_t)ldr * sizeof(T)));
+    if ((size_t)mn > h->ipiv_cap) {
+        if (h->ipiv_dev) RFLU_HIP(hipFree(h->ipiv_dev));
+        h->ipiv_dev = nullptr;
+        h->ipiv_cap = 0;
+        RFLU_HIP(hipMalloc((void**)&h->ipiv_dev, (size_t)mn * sizeof(int64_t)));
+        h->ipiv_cap = (size_t)mn;
+    }
+    const size_t bounce_bytes = (size_t)std::min(chunk, m) * (size_t)n * sizeof(T);
+    RFLU_TRY(ensure_buffer(&h->out_stage, &h->out_stage_bytes, 2 * bounce_bytes));
+    if (h->bounce_bytes < bounce_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            if (h->bounce[i]) RFLU_HIP(hipHostFree(h->bounce[i]));
+            h->bounce[i] = nullptr;
+        }
+        h->bounce_bytes = 0;
+        for (int i = 0; i < 2; ++i)
+            if (hipHostMalloc(&h->bounce[i], bounce_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int k = 0; k < 2; ++k) { if (h->bounce[k]) (void)hipHostFree(h->bounce[k]); h->bounce[k] = nullptr; }
+                return RFLU_OK;   // no pinned memory to be had: the plain sequence needs none
+            }
+        h->bounce_bytes = bounce_bytes;
+    }
+    if (!h->eng_state) {
+        RFLU_HIP(hipMalloc(&h->eng_state, sizeof(EngState)));
+        RFLU_HIP(hipHostMalloc(&h->eng_host, sizeof(EngState), hipHostMallocDefault));
+    }
+    if (!h->eng_rows_final) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return RFLU_OK; }
+        h->eng_rows_final = static_cast<unsigned long long*>(p);
+        void* d = nullptr;
+        RFLU_HIP(hipHostGetDevicePointer(&d, p, 0));
+        h->eng_rows_final_dev = static_cast<unsigned long long*>(d);
+    }
+    *handled = true;
+    *info = 0;
+    EngState* est = static_cast<EngState*>(h->eng_state);
+    T* dA = static_cast<T*>(h->hostA_dev);
+    T* R = static_cast<T*>(h->work);
+    const hipStream_t user = h->stream;
+    const bool trace = h->tune.host_trace != 0;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    __atomic_store_n(h->eng_rows_final, 0ull, __ATOMIC_RELEASE);
+    RFLU_HIP(hipMemsetAsync(&est->arrived, 0, sizeof(unsigned long long), user));
+    RFLU_HIP(hipStreamSynchronize(user));   // (whatever the caller had in flight on this stream is done, the arrival word reads 0)
+    // ---- the way in: a thread of its own (a copy from pageable memory returns when the data has left the host)
+    std::atomic<int> feed_status{RFLU_OK};
+    std::atomic<bool> feed_stop{false};
+    const int device = h->device;
+    const int64_t in_cols = std::max<int64_t>(W, 512);
+    std::thread feeder([&, device]() {
+        if (hipSetDevice(device) != hipSuccess) { feed_status = RFLU_ERR_HIP; return; }
+        for (int64_t c0 = 0; c0 < n && !feed_stop.load(); c0 += in_cols) {
+            const int64_t nc = std::min(in_cols, n - c0);
+            if (hipMemcpy2DAsync(dA + c0 * m, (size_t)m * sizeof(T), A + c0 * lda, (size_t)lda * sizeof(T), (size_t)m * sizeof(T), (size_t)nc,
+                                 hipMemcpyHostToDevice, IN) != hipSuccess ||
+                launch_transpose_on<T>(IN, m, nc, dA + c0 * m, m, R + c0, ldr) != RFLU_OK ||
+                launch_gate_signal_on(IN, &est->arrived, (unsigned long long)(c0 + nc)) != RFLU_OK) {
+                feed_status = RFLU_ERR_HIP;
+                return;
+            }
+        }
+    });
+    struct Join { std::thread& t; std::atomic<bool>& stop; ~Join() { stop = true; if (t.joinable()) t.join(); } } join{feeder, feed_stop};
+    // ---- the way back: runs on this thread once the factorization is enqueued (Handle::before_sync), chunk by chunk as the engine
+    // reports block rows final
+    bool scattered = false;
+    size_t ev_used = 0;
+    auto new_event = [h, &ev_used](hipEvent_t* e) -> int {
+        if (ev_used == h->out_events.size()) {
+            hipEvent_t x;
+            RFLU_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+            h->out_events.push_back(x);
+        }
+        *e = h->out_events[ev_used++];
+        return RFLU_OK;
+    };
+    struct Reset { Handle* h; ~Reset() { h->before_sync = nullptr; h->out_done = false; h->eng_host_mode = false; } } reset{h};
+    h->eng_host_mode = true;
+    h->before_sync = [&]() -> int {
+        hipEvent_t all_done;
+        RFLU_TRY(new_event(&all_done));
+        RFLU_HIP(hipEventRecord(all_done, user));   // the whole factorization (the critical-path stream joins the engine's at its end)
+        if (trace) fprintf(stderr, "[rflu] host entry (engine): enqueue done %.1f ms after the call\n", since(t_call));
+        std::vector<int64_t> ends;
+        for (int64_t r = 0; r < m;) { r = std::min(m, r + chunk); ends.push_back(r); }
+        const size_t nchunks = ends.size();
+        std::vector<hipEvent_t> landed(nchunks);
+        auto start_of = [&](size_t k) { return k == 0 ? (int64_t)0 : ends[k - 1]; };
+        bool everything = false;
+        auto wait_final = [&](int64_t r1) -> int {   // rows [0, r1) final: the engine's word, or the end of everything
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!everything && (int64_t)__atomic_load_n(h->eng_rows_final, __ATOMIC_ACQUIRE) < r1) {
+                const hipError_t q = hipEventQuery(all_done);
+                if (q == hipSuccess) { everything = true; break; }
+                if (q != hipErrorNotReady) { set_error("hipEventQuery failed: %s", hipGetErrorString(q)); return RFLU_ERR_HIP; }
+                if (feed_status.load() != RFLU_OK) { set_error("host entry: feeding the matrix to the device failed"); return RFLU_ERR_HIP; }
+                if (since(t0) > 20000.0) { set_error("host entry: no progress for 20 s"); return RFLU_ERR_TIMEOUT; }
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            return RFLU_OK;
+        };
+        auto send = [&](size_t k) -> int {   // chunk k: final -> transpose into a contiguous piece of the staging copy -> bounce buffer
+            const int64_t r0 = start_of(k), rows = ends[k] - r0;
+            RFLU_TRY(wait_final(ends[k]));
+            T* piece = static_cast<T*>(h->out_stage) + (k & 1) * (size_t)std::min(chunk, m) * (size_t)n;
+            RFLU_TRY(launch_transpose_on<T>(OUT, n, rows, R + r0 * ldr, ldr, piece, rows));
+            RFLU_HIP(hipMemcpyAsync(h->bounce[k & 1], piece, (size_t)rows * (size_t)n * sizeof(T), hipMemcpyDeviceToHost, OUT));
+            RFLU_TRY(new_event(&landed[k]));
+            RFLU_HIP(hipEventRecord(landed[k], OUT));
+            return RFLU_OK;
+        };
+        const int nthreads = std::max(1, std::min(h->tune.host_threads, 64));
+        for (size_t k = 0; k < std::min<size_t>(2, nchunks); ++k) RFLU_TRY(send(k));
+        for (size_t k = 0; k < nchunks; ++k) {
+            RFLU_HIP(hipEventSynchronize(landed[k]));
+            const int64_t r0 = start_of(k), rows = ends[k] - r0;
+            const T* src = static_cast<const T*>(h->bounce[k & 1]);
+            scattered = true;
+            auto scatter = [&](int64_t j0, int64_t j1) {
+                for (int64_t j = j0; j < j1; ++j) memcpy(A + j * lda + r0, src + j * rows, (size_t)rows * sizeof(T));
+            };
+            if (nthreads == 1 || (size_t)rows * (size_t)n * sizeof(T) < ((size_t)8 << 20)) {
+                scatter(0, n);
+            } else {
+                std::vector<std::thread> pool;
+                const int64_t per = (n + nthreads - 1) / nthreads;
+                int64_t done_to = std::min<int64_t>(n, per);
+                try {
+                    for (int t = 1; t < nthreads; ++t) {
+                        pool.emplace_back(scatter, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per));
+                        done_to = std::min<int64_t>(n, (t + 1) * per);
+                    }
+                } catch (...) {
+                }
+                scatter(0, std::min<int64_t>(n, per));
+                if (done_to < n) scatter(done_to, n);
+                for (std::thread& th : pool) th.join();
+            }
+            if (trace) fprintf(stderr, "[rflu] host entry (engine): rows [%lld, %lld) home at %.1f ms\n", (long long)r0, (long long)ends[k], since(t_call));
+            if (k + 2 < nchunks) RFLU_TRY(send(k + 2));
+        }
+        h->out_done = true;
+        return RFLU_OK;
+    };
+    int rc = getrf_rm<T>(h, m, n, R, ldr, (pivot || ipiv) ? h->ipiv_dev : nullptr, pivot, blocksize, info);
+    feed_stop = true;
+    if (feeder.joinable()) feeder.join();
+    if (rc == RFLU_OK && feed_status.load() != RFLU_OK) { set_error("host entry: feeding the matrix to the device failed"); rc = feed_status.load(); }
+    if (rc != RFLU_OK) {
+        // a failed call leaves the caller's matrix as it was (the device copy of the input is never written by the factorization)
+        (void)hipDeviceSynchronize();
+        if (scattered)
+            (void)hipMemcpy2D(A, (size_t)lda * sizeof(T), dA, (size_t)m * sizeof(T), (size_t)m * sizeof(T), (size_t)n, hipMemcpyDeviceToHost);
+        return rc;
+    }
+    if (!h->out_done) {   // (cannot happen: before_sync either brings everything home or fails)
+        set_error("host entry: the factors did not travel back");
+        return RFLU_ERR_ARG;
+    }
+    if (ipiv) RFLU_HIP(hipMemcpyAsync(ipiv, h->ipiv_dev, (size_t)mn * sizeof(int64_t), hipMemcpyDeviceToHost, user));
+    RFLU_HIP(hipStreamSynchronize(user));
+    RFLU_HIP(hipStreamSynchronize(IN));
+    return RFLU_OK;
+}
+
 // host entry: stage through device buffers owned by the handle
 template <typename T>
 static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv, int pivot, int64_t blocksize,
@@ -1372,6 +1592,11 @@ static int getrf_host(Handle* h, int64_t m, int64_t n, T* A, int64_t lda, int64_
     *info = 0;
     const int64_t mn = std::min(m, n);
     if (mn == 0) return RFLU_OK;
+    {   // the way in overlapped with the factorization (the update engine's dataflow waits for columns; the stream schedules cannot)
+        bool handled = false;
+        const int rc = getrf_host_engine<T>(h, m, n, A, lda, ipiv, pivot, blocksize, info, &handled);
+        if (handled || rc != RFLU_OK) return rc;
+    }
     RFLU_TRY(ensure_buffer(&h->hostA_dev, &h->hostA_bytes, (size_t)m * (size_t)n * sizeof(T)));
     if ((size_t)mn > h->ipiv_cap) {
         if (h->ipiv_dev) RFLU_HIP(hipFree(h->ipiv_dev));
@@ -1765,19 +1990,6 @@ int rflu_debug_gate_stamps(rflu_handle_t handle, long long* out)
     CHECK_HANDLE(handle);
     if (!H(handle)->gate_stamps) { set_error("no gate trace (set RFLU_GATE_TRACE=1)"); return RFLU_ERR_ARG; }
     RFLU_HIP(hipMemcpy(out, H(handle)->gate_stamps, 3 * 4096 * sizeof(long long), hipMemcpyDeviceToHost));
-    return RFLU_OK;
-}
-
-// measurement only (scripts/engine_trace.py): per block column of the last factorization that used the update engine, the wall clock
-// (100 MHz ticks) at which its column block had received every update (t_ready) and at which its panel was published (t_panel)
-int rflu_debug_engine_times(rflu_handle_t handle, long long* t_ready, long long* t_panel, int n)
-{
-    CHECK_HANDLE(handle);
-    Handle* h = H(handle);
-    if (!h->eng_state || n < 0 || n > ENG_MAX_CB) { set_error("no engine state (or n out of range)"); return RFLU_ERR_ARG; }
-    std::vector<EngCB> tmp((size_t)n);
-    RFLU_HIP(hipMemcpy(tmp.data(), static_cast<EngState*>(h->eng_state)->cb, (size_t)n * sizeof(EngCB), hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; ++i) { t_ready[i] = tmp[i].t_ready; t_panel[i] = 0; }
     return RFLU_OK;
 }
 

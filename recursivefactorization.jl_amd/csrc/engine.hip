@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
     long long idle_since = -1;
     int idle_rounds = 0;
     int cb_lo = 0;             // column blocks in front of this one have nothing left for the main scan (monotone)
+    int fin_b = 0;             // workgroup 0: block rows [0, fin_b) have been reported final (EngArgs::rows_final)
 
     auto leaves_done = [&]() -> int {
         const unsigned long long v = eng_load(a.leaf_gate);
@@ -245,9 +246,33 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         if (tid < 64) {
             int kind = ENG_NONE, sel_cb = 0, sel_unit = 0;
             unsigned sel_seq = 0;
+            // ---- host entry: how many rows of the factors are final (workgroup 0 looks once per round).  Block row b is final when
+            // nothing will write to it any more: every operation on column block b is complete, the leaves of block column b have
+            // reached column block b + 1, BIG(b) is complete everywhere, and the interchanges of block column b have reached its own
+            // columns and every column block to its left (later block columns only move rows below)
+            if (a.rows_final && blockIdx.x == 0 && fin_b < a.g.nbp) {
+                for (;;) {
+                    const int b = fin_b;
+                    if (b >= a.g.nbp) break;
+                    bool fin = (unsigned)(eng_load(&st->cb[b].claim) >> 32) == ENG_SEQ_DONE &&
+                               (b + 1 >= a.g.ncb || (int)eng_load(&st->cb[b + 1].prog) >= eng_leafn_end(a.g, b + 1)) &&
+                               (int)eng_load(&st->cb[b].bigdone) >= eng_big_users(a.g, b) &&
+                               leaves_done() >= b * (a.g.W / NB) + eng_leaves_of_block(a.g, b);
+                    if (fin && a.g.pivot)
+                        fin = (int)eng_load(&st->cb[b].lprog) >= 1 && (int)eng_load(&st->cb[b].leftdone) >= b;
+                    if (!fin) break;
+                    fin_b = b + 1;
+                    if (lane == 0) {
+                        const int rows = fin_b >= a.g.nbp && a.g.nbp * a.g.W >= a.g.mn ? a.g.m : min(fin_b * a.g.W, a.g.m);
+                        // (the last block row takes the rows below the square part along: nothing writes them after the last panel)
+                        __hip_atomic_store(a.rows_final, (unsigned long long)rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
             for (int attempt = 0; attempt < 4 && kind == ENG_NONE; ++attempt) {
                 if (eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0) { kind = ENG_EXIT; break; }
                 const int pd = leaves_done();
+                const int have = a.arrived ? (int)eng_load(a.arrived) : a.g.n;   // columns in place (host entry: they arrive while we run)
                 // ---- main units: one lane per column block -----------------------------------------------------------------
                 int best = INT_MAX;
                 int first_live = INT_MAX;
@@ -261,11 +286,19 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         if (seq != ENG_SEQ_DONE) {
                             live = true;
                             const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
-                            bool ok = o.need <= pd && (int)u < eng_units_of(o, (int)(seq & 1u), a.g.m);
+                            bool ok = o.need <= pd && (int)u < eng_units_of(o, (int)(seq & 1u), a.g.m) && min(a.g.n, (cb + 1) * a.g.W) <= have;
                             // a block column as a whole is applied with ITS interchanges complete on all its columns (engine.hpp)
                             if (ok && o.type == ENG_OP_BIG && (seq & 1u) == 0 && eng_big_waits_for_left(a.g, (int)(seq >> 1)))
                                 ok = eng_load(&st->cb[seq >> 1].lprog) >= 1;
-                            if (ok) key = a.policy ? (((o.j0 / NB) << 10) | cb) : cb;
+                            if (ok) {
+                                key = a.policy ? (((o.j0 / NB) << 10) | cb) : ((1 << 24) | cb);
+                                // host entry: a block row can leave only when the panel has reached EVERY column block; with the
+                                // leftmost-first rule alone the far right is served last and the way back starts when the
+                                // factorization ends.  A whole-block-column operation that lags the chain by `lag` block columns
+                                // or more goes first, oldest panel first.
+                                if (a.x[3] > 0 && o.type == ENG_OP_BIG && pd / (a.g.W / NB) - (int)(seq >> 1) >= a.x[3])
+                                    key = ((int)(seq >> 1) << 10) | cb;
+                            }
                         }
                     }
                     const unsigned long long lv = __ballot(live);
@@ -274,7 +307,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
                     best = min(best, mk);
-                    if (a.policy == 0 && best != INT_MAX) break;   // leftmost first: nothing further right can beat it
+                    if (a.policy == 0 && a.x[3] <= 0 && best != INT_MAX) break;   // leftmost first: nothing further right can beat it
                 }
                 if (first_live != INT_MAX) cb_lo = first_live;
                 if (best != INT_MAX) {
@@ -415,7 +448,6 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         __hip_atomic_store(&c->prog, (unsigned long long)(ns >> 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (ns >= end) {
-                        c->t_ready = wall_clock64();
                         __hip_atomic_store(&c->claim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
@@ -432,6 +464,8 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     const int nleft = eng_nleft(a.g, cb);
                     int nk = (int)seq + 1;
                     while (nk < nleft && eng_left_units<T>(a.g, cb, nk) == 0) ++nk;
+                    for (int k = max((int)seq, 1); k < nk; ++k)   // (the left ops just completed: block columns cb + k have reached this column block)
+                        __hip_atomic_fetch_add(&st->cb[cb + k].leftdone, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&c->lprog, (unsigned long long)nk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     if (nk >= nleft) {
                         __hip_atomic_store(&c->lclaim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

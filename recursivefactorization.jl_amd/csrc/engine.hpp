@@ -26,13 +26,13 @@ struct EngCB {
     unsigned long long lclaim;   // deferred interchanges on this (finished) column block: (left op << 32) | next unit
     unsigned long long ldone;
     unsigned long long prog;     // operations completed (the critical-path stream waits for prog > op in front of a leaf's lookahead columns)
-    long long t_ready;           // wall clock (100 MHz) when the last operation completed (rflu_debug_engine_times)
+    unsigned long long leftdone; // column blocks to the left that have received THIS block column's interchanges (left op >= 1 of theirs)
     unsigned long long lprog;    // left operations completed (lprog >= 1: the block column's own later interchanges have reached all its columns)
     unsigned long long bigdone;  // column blocks that have completed BIG(this block column)
 };
 
 struct EngState {
-    unsigned long long unused0;
+    unsigned long long arrived;      // host entry: columns [0, arrived) of the row-major workspace are in place (written by the feeding stream)
     unsigned long long remaining;    // column-block sequences (main and left) still unfinished: the engine exits at 0
     unsigned long long abort;        // != 0: leave (timeout somewhere)
     unsigned long long pad[5];
@@ -192,6 +192,10 @@ struct EngArgs {
     const unsigned long long* leaf_gate;   // the critical-path stream's counter: gate_base + (leaves completed incl. their lookahead launch)
     unsigned long long gate_base;
     int64_t* info;  // info[1] bit 0: timeout
+    // host entry (driver.cpp: getrf_host_engine): the matrix arrives block column by block column while the factorization runs, and
+    // finished block rows leave the same way
+    const unsigned long long* arrived;     // columns [0, *arrived) of R are in place (nullptr: all of them)
+    unsigned long long* rows_final;        // host-visible word: rows [0, *rows_final) of the factors are final (nullptr: nobody asks)
     int gemm_flags;
     int x[8];       // experiment switches (Tune::engine_x)
 };

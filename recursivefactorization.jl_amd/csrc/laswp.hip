@@ -318,6 +318,17 @@ int launch_transpose(Handle* h, int64_t rows_out, int64_t cols_out, const T* in,
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }
+template <typename T>
+int launch_transpose_on(hipStream_t st, int64_t rows_out, int64_t cols_out, const T* in, int64_t ld_in, T* out, int64_t ld_out)
+{
+    if (rows_out <= 0 || cols_out <= 0) return RFLU_OK;
+    dim3 grid((unsigned)((cols_out + 63) / 64), (unsigned)((rows_out + 63) / 64));
+    hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, st, rows_out, cols_out, in, ld_in, out, ld_out);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+template int launch_transpose_on<double>(hipStream_t, int64_t, int64_t, const double*, int64_t, double*, int64_t);
+template int launch_transpose_on<float>(hipStream_t, int64_t, int64_t, const float*, int64_t, float*, int64_t);
 template int launch_transpose<double>(Handle*, int64_t, int64_t, const double*, int64_t, double*, int64_t);
 template int launch_transpose<float>(Handle*, int64_t, int64_t, const float*, int64_t, float*, int64_t);
 
@@ -480,6 +491,13 @@ __global__ void gate_wait_kernel(const unsigned long long* flag, unsigned long l
 int launch_gate_signal(Handle* h, unsigned long long* flag, unsigned long long value, long long* stamp)
 {
     hipLaunchKernelGGL(gate_signal_kernel, dim3(1), dim3(1), 0, h->stream, flag, value, stamp);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
+}
+
+int launch_gate_signal_on(hipStream_t st, unsigned long long* flag, unsigned long long value)
+{
+    hipLaunchKernelGGL(gate_signal_kernel, dim3(1), dim3(1), 0, st, flag, value, (long long*)nullptr);
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }

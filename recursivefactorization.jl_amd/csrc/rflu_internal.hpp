@@ -114,6 +114,7 @@ struct Tune {
     int engine_policy = 0;             // RFLU_ENGINE_POLICY: 0 = leftmost column block first, 1 = oldest panel piece first
     int engine_wgs = 0;                // RFLU_ENGINE_WGS: resident workgroups (0: two per CU of the update mask)
     int64_t engine_rows = 4096;        // RFLU_ENGINE_ROWS: block columns whose panels are taller than this go through the engine
+    int engine_host = 1;               // RFLU_ENGINE_HOST: host-pointer entry (rflu_getrf_*) through the engine: the way in overlaps the factorization
     int engine_x[8] = {};              // RFLU_ENGINE_X0..7: experiment switches (X0 = 1: no release fence, X1 = 1: no acquire -- timing only)
     void load_env();                   // driver.cpp
 };
@@ -202,7 +203,11 @@ struct Handle {
     bool eng_attr_set[2] = {false, false};    // same for the persistent update engine (engine.hip)
     void* eng_state = nullptr;                // device: EngState (engine.hpp)
     void* eng_host = nullptr;                 // pinned host image of its initial value
-    bool eng_active = false;                  // a factorization's engine is resident (factor_engine .. the join with its stream)
+    bool eng_active = false;                  // a factorization's engine is resident (factor_leafwise in engine mode .. the join with its stream)
+    // host entry through the engine (driver.cpp: getrf_host_engine): the matrix arrives while it is being factored
+    bool eng_host_mode = false;
+    unsigned long long* eng_rows_final = nullptr;       // pinned host word (rows of the factors that are final), ...
+    unsigned long long* eng_rows_final_dev = nullptr;   // ... its device address
     int64_t* info_pinned = nullptr;
 
     // timers
@@ -329,6 +334,10 @@ template <typename T>
 int launch_panel_pair(Handle* h, T* R, int64_t ld, int64_t m, int64_t r0, int64_t c0, int64_t* ipiv);
 template <typename T>
 int launch_transpose(Handle* h, int64_t rows_out, int64_t cols_out, const T* in, int64_t ld_in, T* out, int64_t ld_out);
+// the same on an explicit stream, touching nothing of the handle (a second host thread feeds the matrix in: getrf_host_engine)
+template <typename T>
+int launch_transpose_on(hipStream_t st, int64_t rows_out, int64_t cols_out, const T* in, int64_t ld_in, T* out, int64_t ld_out);
+int launch_gate_signal_on(hipStream_t st, unsigned long long* flag, unsigned long long value);
 template <typename T>
 int launch_fill_uniform(Handle* h, T* A, int64_t m, int64_t n, int64_t ld, int row_major, uint64_t seed,
                         int64_t M_global, int64_t i0, int64_t j0, double diag_add);

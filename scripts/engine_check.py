@@ -71,12 +71,3 @@ if mode in ("time", "all"):
             _, _, _, info, t = factor(n, "f64", 0, env, reps=4)
             print(f"n={n} {env}: info {info} best {t:.2f} ms", flush=True)
 
-if mode in ("trace", "all"):
-    # per column block: when it had received everything the engine owes it (us since the first one)
-    for n, env in ((16384, {"RFLU_ENGINE": "1"}),):
-        _, _, _, info, t = factor(n, "f64", 0, env, reps=2)
-        nb = n // 512
-        tr = (ctypes.c_longlong * nb)(); tp = (ctypes.c_longlong * nb)()
-        h.call("rflu_debug_engine_times", tr, tp, nb)
-        t0 = min(x for x in tr if x)
-        print(f"n={n} {env}: {t:.2f} ms; column block complete [us]: " + " ".join(f"{(x - t0) / 100.0:.0f}" if x else "-" for x in tr), flush=True)

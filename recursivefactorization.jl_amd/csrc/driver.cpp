@@ -986,7 +986,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             const int end = 2 * eng_nops(geo, cb);
             int sq = 0;
             while (sq < end && eng_units_of(eng_op(geo, cb, sq >> 1), sq & 1, geo.m) == 0) ++sq;
-            c.prog = (unsigned long long)(sq >> 1);
+            c.prog = 2ull * (unsigned long long)(sq >> 1);
             c.claim = sq < end ? (unsigned long long)sq << 32 : (unsigned long long)ENG_SEQ_DONE << 32;
             img->remaining += sq < end;
             const int nleft = eng_nleft(geo, cb);
@@ -1058,7 +1058,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                 if (eng_end > 0 && (g - 1) / LPB < eng_end) {   // ... through the engine: LEAF(g - 1) is complete on the lookahead strip's column block
                     const int cb_la = (int)(la0 / W);
                     wflag = &est->cb[cb_la].prog;
-                    wval = (unsigned long long)eng_leaf_op_index(geo, cb_la, (int)(g - 1)) + 1;
+                    wval = 2ull * (unsigned long long)eng_leaf_op_index(geo, cb_la, (int)(g - 1)) + 1;   // (its first tile column: engine.hpp, prog)
                 } else {
                     wflag = h->gate_ptr[la0 < std::min(((c0 - NB) / W + 1) * W, n) ? 1 : 2];
                 }
@@ -1116,7 +1116,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                     // behind the update engine: the next block column is up to date when all its operations are complete
                     if (rc == RFLU_OK && b + 1 < (n + W - 1) / W && eng_nops(geo, (int)(b + 1)) > 0) {
                         h->stream = S;
-                        rc = launch_eng_wait(h, &est->cb[b + 1].prog, (unsigned long long)eng_nops(geo, (int)(b + 1)));
+                        rc = launch_eng_wait(h, &est->cb[b + 1].prog, 2ull * (unsigned long long)eng_nops(geo, (int)(b + 1)));
                     }
                 } else {
                 if (rc == RFLU_OK) rc = get_event(h, evU1(b - 1), &e);

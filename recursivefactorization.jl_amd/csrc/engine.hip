@@ -20,7 +20,8 @@
 // fetch-and-add on its claim word -> agent-scope acquire -> run the unit -> agent-scope release -> count it done; the last finisher
 // of a sequence publishes the next one }.  An operation is eligible once the critical-path stream's leaf counter says that the
 // leaves it applies are factored (and their diagonal inverses / move lists written); a column block publishes how many of its
-// operations are complete (`prog`), which the critical-path stream waits for in front of a leaf's lookahead columns.  No workgroup
+// operations are complete (`prog`, with a half step when a leaf window's first tile column is), which the critical-path stream waits for
+// in front of a leaf's lookahead columns.  No workgroup
 // ever waits for a particular other workgroup: a unit is claimed when everything it reads is final, so residency is a matter of
 // speed, not of correctness.  The interchanges that later leaves owe the FINISHED columns to their left are units of lowest priority.
 // Inter-workgroup visibility follows MI355X_MICROARCH.md ("Workgroup dispatch ..."): producer = every wave drains its stores,
@@ -172,16 +173,24 @@ __device__ __attribute__((noinline)) void eng_gemm_unit(const EngArgs<T>& a, con
     g.tiles_m = (g.M + G_BM - 1) / G_BM;
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
     g.vec_ok = (reinterpret_cast<uintptr_t>(a.R) % 16 == 0) && (a.ld % VW == 0) && (o.c_lo % VW == 0) && (o.j0 % VW == 0);
-    g.flags = a.gemm_flags;
+    g.flags = a.gemm_flags | ((a.x[2] & 1) ? 4 : 0);   // x[2] = 1: write-through C stores, no release fence behind a tile
     g.na_tiles_n = 0; g.sig_flag = nullptr; g.sig_val = 0; g.sig_cnt = nullptr;
     // G_GROUP_M tile rows are walked together, column after column: consecutive claims share the B panel, then the A panels
-    const int per_group = G_GROUP_M * g.tiles_n;
-    const int group = t / per_group;
-    const int first_m = group * G_GROUP_M;
-    const int gsz = min(g.tiles_m - first_m, G_GROUP_M);
-    const int in_group = t - group * per_group;
-    const int tile_m = first_m + in_group % gsz;
-    const int tile_n = in_group / gsz;
+    int tile_m, tile_n;
+    if (o.type == ENG_OP_LEAF) {
+        // a leaf's window, first tile column first: the critical-path stream waits for exactly those columns (the next leaf's
+        // lookahead strip is the leftmost of the window) and is told when they are complete, not when the whole window is
+        tile_n = t / g.tiles_m;
+        tile_m = t - tile_n * g.tiles_m;
+    } else {
+        const int per_group = G_GROUP_M * g.tiles_n;
+        const int group = t / per_group;
+        const int first_m = group * G_GROUP_M;
+        const int gsz = min(g.tiles_m - first_m, G_GROUP_M);
+        const int in_group = t - group * per_group;
+        tile_m = first_m + in_group % gsz;
+        tile_n = in_group / gsz;
+    }
     const int m0 = tile_m * G_BM, n0 = tile_n * G_BN;
     const bool full_mn = g.vec_ok && (m0 + G_BM <= g.M) && (n0 + G_BN <= g.N);
     if (full_mn && (g.K % G_BK) == 0 && g.K >= 2 * G_BK) gemm_tile<T, true, true>(g, smem, m0, n0);
@@ -236,6 +245,9 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
     int idle_rounds = 0;
     int cb_lo = 0;             // column blocks in front of this one have nothing left for the main scan (monotone)
     int fin_b = 0;             // workgroup 0: block rows [0, fin_b) have been reported final (EngArgs::rows_final)
+    // x[4] = m > 0: workgroups with blockIdx % m == 1;  x[5] = k > 0: the workgroups of k XCDs (blockIdx % 8 in [1, k]);  x[6] = j > 0: of those, only blockIdx / 8 < j
+    bool leaf_only = a.x[4] > 0 && (int)(blockIdx.x % (unsigned)a.x[4]) == 1;
+    if (a.x[5] > 0) leaf_only = (int)(blockIdx.x & 7) >= 1 && (int)(blockIdx.x & 7) <= a.x[5] && (a.x[6] <= 0 || (int)(blockIdx.x >> 3) < a.x[6]);
 
     auto leaves_done = [&]() -> int {
         const unsigned long long v = eng_load(a.leaf_gate);
@@ -255,7 +267,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     const int b = fin_b;
                     if (b >= a.g.nbp) break;
                     bool fin = (unsigned)(eng_load(&st->cb[b].claim) >> 32) == ENG_SEQ_DONE &&
-                               (b + 1 >= a.g.ncb || (int)eng_load(&st->cb[b + 1].prog) >= eng_leafn_end(a.g, b + 1)) &&
+                               (b + 1 >= a.g.ncb || (int)eng_load(&st->cb[b + 1].prog) >= 2 * eng_leafn_end(a.g, b + 1)) &&
                                (int)eng_load(&st->cb[b].bigdone) >= eng_big_users(a.g, b) &&
                                leaves_done() >= b * (a.g.W / NB) + eng_leaves_of_block(a.g, b);
                     if (fin && a.g.pivot)
@@ -287,6 +299,9 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                             live = true;
                             const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
                             bool ok = o.need <= pd && (int)u < eng_units_of(o, (int)(seq & 1u), a.g.m) && min(a.g.n, (cb + 1) * a.g.W) <= have;
+                            // every x[4]-th workgroup serves the leaf-wise window only: the K = 64 operations the chain of leaves waits
+                            // for find a free workgroup at once instead of queueing behind 127-us tiles of the block-column updates
+                            if (leaf_only && o.type == ENG_OP_BIG) ok = false;
                             // a block column as a whole is applied with ITS interchanges complete on all its columns (engine.hpp)
                             if (ok && o.type == ENG_OP_BIG && (seq & 1u) == 0 && eng_big_waits_for_left(a.g, (int)(seq >> 1)))
                                 ok = eng_load(&st->cb[seq >> 1].lprog) >= 1;
@@ -352,7 +367,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                                 bool ok;
                                 if (lk == 0) {   // every LEAF op of this block column is complete: here and on the column block to the right
                                     ok = (unsigned)(eng_load(&st->cb[cb].claim) >> 32) == ENG_SEQ_DONE &&
-                                         (cb + 1 >= a.g.ncb || (int)eng_load(&st->cb[cb + 1].prog) >= eng_leafn_end(a.g, cb + 1));
+                                         (cb + 1 >= a.g.ncb || (int)eng_load(&st->cb[cb + 1].prog) >= 2 * eng_leafn_end(a.g, cb + 1));
                                 } else {         // nobody reads this block column's L any more
                                     ok = (int)eng_load(&st->cb[cb].bigdone) >= eng_big_users(a.g, cb);
                                 }
@@ -378,7 +393,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                                 if (leaves_done() < eng_left_need(a.g, cb, (int)lk)) return false;
                                 if (lk == 0)
                                     return (unsigned)(eng_load(&st->cb[cb].claim) >> 32) == ENG_SEQ_DONE &&
-                                           (cb + 1 >= a.g.ncb || (int)eng_load(&st->cb[cb + 1].prog) >= eng_leafn_end(a.g, cb + 1));
+                                           (cb + 1 >= a.g.ncb || (int)eng_load(&st->cb[cb + 1].prog) >= 2 * eng_leafn_end(a.g, cb + 1));
                                 return (int)eng_load(&st->cb[cb].bigdone) >= eng_big_users(a.g, cb);
                             };
                             while (!left_ok() && eng_load(&st->abort) == 0) {
@@ -411,7 +426,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 }
                 break;
             }
-            idle_rounds = min(idle_rounds + 1, 8);
+            idle_rounds = min(idle_rounds + 1, leaf_only ? 4 : (a.x[7] > 0 ? a.x[7] : 8));
             for (int i = 0; i < idle_rounds; ++i) __builtin_amdgcn_s_sleep(32);
             __syncthreads();   // s_sel is rewritten by wave 0 in the next round
             continue;
@@ -429,11 +444,23 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            if (!(a.x[0] & 1)) eng_release();
+            // a Schur tile stored write-through has nothing left in this XCD's L2 (its stores are acknowledged: s_waitcnt above)
+            if (!(a.x[0] & 1) && !((a.x[2] & 1) && kind == ENG_MAIN && (seq & 1u) != 0)) eng_release();
             EngCB* c = &st->cb[cb];
             if (kind == ENG_MAIN) {
                 const int units = eng_units(a, cb, seq);
-                const unsigned long long d = __hip_atomic_fetch_add(&c->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                // done = finished units (low word) | finished units of a leaf window's FIRST tile column (high word)
+                const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+                const int tiles_m = (a.g.m - (o.j0 + o.jb) + G_BM - 1) / G_BM;
+                const bool first_col = (seq & 1u) != 0 && o.type == ENG_OP_LEAF && unit < tiles_m;
+                const unsigned long long dd = __hip_atomic_fetch_add(&c->done, 1ull + (first_col ? 1ull << 32 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                                              1ull + (first_col ? 1ull << 32 : 0ull);
+                const unsigned long long d = dd & 0xffffffffull;
+                if (first_col && (int)(dd >> 32) == tiles_m && (int)d != units) {
+                    // the window's first tile column is complete: the critical path may go on (prog = 2 * completed ops + 1)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                    __hip_atomic_store(&c->prog, 2ull * (unsigned long long)(seq >> 1) + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if ((int)d == units) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                     eng_store(&c->done, 0ull);
@@ -445,7 +472,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         for (unsigned k = seq >> 1; k < (ns >> 1); ++k)   // (the operations just completed, skipped ones included)
                             if ((int)k < eng_nbig(a.g, cb))
                                 __hip_atomic_fetch_add(&st->cb[k].bigdone, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&c->prog, (unsigned long long)(ns >> 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&c->prog, 2ull * (unsigned long long)(ns >> 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (ns >= end) {
                         __hip_atomic_store(&c->claim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -25,7 +25,8 @@ struct EngCB {
     unsigned long long done;     // finished units of the current sequence
     unsigned long long lclaim;   // deferred interchanges on this (finished) column block: (left op << 32) | next unit
     unsigned long long ldone;
-    unsigned long long prog;     // operations completed (the critical-path stream waits for prog > op in front of a leaf's lookahead columns)
+    unsigned long long prog;     // 2 * (operations completed) + (the first tile column of the current leaf window is complete): the critical-path
+                                 // stream waits for prog >= 2 * op + 1 in front of a leaf's lookahead columns (the leftmost of that window)
     unsigned long long leftdone; // column blocks to the left that have received THIS block column's interchanges (left op >= 1 of theirs)
     unsigned long long lprog;    // left operations completed (lprog >= 1: the block column's own later interchanges have reached all its columns)
     unsigned long long bigdone;  // column blocks that have completed BIG(this block column)

@@ -179,6 +179,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& g, T* smem, const i
     // tile before its first LDS fill (11 us of a 127 us tile, scripts/gemm_phase_trace.py).  So the last G_CSPLIT..3 rows of
     // fragments are requested after the first barrier: 8 + 48 loads in flight at the wait, vmcnt(48).
     const bool ntc = (g.flags & 2) != 0;
+    const bool wt = (g.flags & 4) != 0;
     gload(0);
     // For a fixed (i,j,r) sixteen lanes cover 16 consecutive columns of one row of C.
     acc_t acc[4][4];
@@ -294,7 +295,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& g, T* smem, const i
                     if (full_mn || col < g.N) {
                         if (C_FIRST) {
                             const T out = NEGACC ? -acc[i][j][r] : acc[i][j][r];
-                            if (ntc) __builtin_nontemporal_store(out, crow_p + j * 16);
+                            // flags bit 2: write-through (sc1) stores -- the resident engine publishes a finished tile without an
+                            // agent-scope release fence, i.e. without writing back its whole XCD's L2 (engine.hip)
+                            if (wt) __hip_atomic_store(crow_p + j * 16, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else if (ntc) __builtin_nontemporal_store(out, crow_p + j * 16);
                             else crow_p[j * 16] = out;
                         } else {
                             crow_p[j * 16] = crow_p[j * 16] - acc[i][j][r];

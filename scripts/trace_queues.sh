@@ -9,5 +9,6 @@ rocprofv3 --kernel-trace -d $OUT/trace -- python bench.py --size $SIZE --steps 2
 DB=$(find $OUT/trace -name "*.db" | head -1)
 python scripts/rocpd_queues.py $DB 1 x > $OUT/queues_$SIZE.txt 2>&1 || true
 python scripts/rocpd_blocks.py $DB 1 > $OUT/blocks_$SIZE.txt 2>&1 || true
+python scripts/rocpd_summary.py $DB > $OUT/summary_$SIZE.txt 2>&1 || true
 rm -rf $OUT/trace
 cat $OUT/queues_$SIZE.txt

@@ -109,6 +109,7 @@ void Tune::load_env()
     env_get("RFLU_ENGINE_WGS", engine_wgs);
     env_get("RFLU_ENGINE_ROWS", engine_rows);
     env_get("RFLU_ENGINE_HOST", engine_host);
+    env_get("RFLU_ENGINE_WC", engine_wc);
     for (int i = 0; i < 8; ++i) {
         char name[32];
         snprintf(name, sizeof(name), "RFLU_ENGINE_X%d", i);
@@ -976,8 +977,11 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         }
         est = static_cast<EngState*>(h->eng_state);
         EngState* img = static_cast<EngState*>(h->eng_host);
-        geo.m = (int)m; geo.n = (int)n; geo.mn = (int)mn; geo.W = (int)W; geo.nbp = (int)eng_end; geo.ncb = (int)((n + W - 1) / W);
+        geo.m = (int)m; geo.n = (int)n; geo.mn = (int)mn; geo.W = (int)W; geo.nbp = (int)eng_end;
+        geo.Wc = (h->tune.engine_wc >= 128 && h->tune.engine_wc % 128 == 0 && W % h->tune.engine_wc == 0) ? h->tune.engine_wc : (int)W;
+        geo.ncb = (int)((n + geo.Wc - 1) / geo.Wc);
         geo.pivot = f.pivot;
+        if (geo.ncb > ENG_MAX_CB) { geo.Wc = (int)W; geo.ncb = (int)((n + W - 1) / W); }
         const size_t bytes = offsetof(EngState, cb) + (size_t)geo.ncb * sizeof(EngCB);
         const size_t skip = offsetof(EngState, remaining);   // (the arrival word in front belongs to the feeding stream: getrf_host_engine)
         memset(img, 0, bytes);
@@ -994,6 +998,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             while (lk < nleft && eng_left_units<T>(geo, cb, lk) == 0) ++lk;
             c.lclaim = lk < nleft ? (unsigned long long)lk << 32 : (unsigned long long)ENG_SEQ_DONE << 32;
             c.lprog = (unsigned long long)lk;   // (left ops without units count as done)
+            if (nleft > 0 && lk > 0) img->cb[eng_first_cb(geo, eng_pb(geo, cb))].leftdone += 1ull << 32;   // ... towards the block column's own count too
             img->remaining += lk < nleft;
         }
         // the initial state travels on the caller's stream, in front of everything the engine is going to wait for
@@ -1007,6 +1012,26 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         a.arrived = h->eng_host_mode ? &est->arrived : nullptr;
         a.rows_final = h->eng_host_mode ? h->eng_rows_final_dev : nullptr;
         for (int i = 0; i < 8; ++i) a.x[i] = h->tune.engine_x[i];
+        a.trace = nullptr;
+        static long long* eng_trace_buf = nullptr;   // measurement only (RFLU_ENGINE_TRACE=1): stamps of the leaf windows, printed at the next call
+        if (env_str("RFLU_ENGINE_TRACE")) {
+            if (!eng_trace_buf) RFLU_HIP(hipMalloc((void**)&eng_trace_buf, 4096 * 4 * sizeof(long long)));
+            else {
+                std::vector<long long> hs(4096 * 4);
+                RFLU_HIP(hipMemcpy(hs.data(), eng_trace_buf, hs.size() * sizeof(long long), hipMemcpyDeviceToHost));
+                double s01 = 0, s12 = 0, s23 = 0, sq = 0; int cnt = 0;
+                for (int g = 1; g + 1 < (int)nleaf && g < 4095; ++g) {
+                    if (!hs[g * 4] || !hs[g * 4 + 3] || !hs[(g - 1) * 4 + 3]) continue;
+                    s01 += (hs[g * 4 + 1] - hs[g * 4]) / 100.0; s12 += (hs[g * 4 + 2] - hs[g * 4 + 1]) / 100.0; s23 += (hs[g * 4 + 3] - hs[g * 4 + 2]) / 100.0;
+                    sq += (hs[g * 4] - hs[(g - 1) * 4 + 3]) / 100.0; ++cnt;
+                }
+                if (cnt) fprintf(stderr, "[rflu] engine trace (previous call, %d leaf windows on their first column block): first claim -> stage 0 done %.1f us, -> first tile claimed %.1f, -> window complete %.1f; previous window complete -> first claim %.1f us\n", cnt, s01 / cnt, s12 / cnt, s23 / cnt, sq / cnt);
+                for (int g = 40; g < 44 && g + 1 < (int)nleaf; ++g)
+                    fprintf(stderr, "   leaf %d: %.1f %.1f %.1f | since previous window complete %.1f\n", g, (hs[g * 4 + 1] - hs[g * 4]) / 100.0, (hs[g * 4 + 2] - hs[g * 4 + 1]) / 100.0, (hs[g * 4 + 3] - hs[g * 4 + 2]) / 100.0, (hs[g * 4] - hs[(g - 1) * 4 + 3]) / 100.0);
+            }
+            RFLU_HIP(hipMemsetAsync(eng_trace_buf, 0, 4096 * 4 * sizeof(long long), P));
+            a.trace = eng_trace_buf;
+        }
         // host entry: whole-block-column operations that lag the chain by this many block columns go first (engine.hip), so that
         // block rows become final -- and leave -- while the factorization runs (N=16384: 3: 123 ms, 5: 109-110, 8: 112, none: 118)
         if (h->eng_host_mode && a.x[3] == 0) a.x[3] = 5;
@@ -1056,7 +1081,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             unsigned long long wval = g > 0 ? val(g - 1) : 0;
             if (la1 > la0 && g > gfirst) {
                 if (eng_end > 0 && (g - 1) / LPB < eng_end) {   // ... through the engine: LEAF(g - 1) is complete on the lookahead strip's column block
-                    const int cb_la = (int)(la0 / W);
+                    const int cb_la = (int)(la0 / geo.Wc);
                     wflag = &est->cb[cb_la].prog;
                     wval = 2ull * (unsigned long long)eng_leaf_op_index(geo, cb_la, (int)(g - 1)) + 1;   // (its first tile column: engine.hpp, prog)
                 } else {
@@ -1114,10 +1139,11 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                 hipEvent_t e;
                 if (eng_end > 0 && b == eng_end) {
                     // behind the update engine: the next block column is up to date when all its operations are complete
-                    if (rc == RFLU_OK && b + 1 < (n + W - 1) / W && eng_nops(geo, (int)(b + 1)) > 0) {
-                        h->stream = S;
-                        rc = launch_eng_wait(h, &est->cb[b + 1].prog, 2ull * (unsigned long long)eng_nops(geo, (int)(b + 1)));
-                    }
+                    for (int c = eng_first_cb(geo, (int)(b + 1)); rc == RFLU_OK && c < eng_first_cb(geo, (int)(b + 1)) + eng_cbs_of_block(geo, (int)(b + 1)); ++c)
+                        if (eng_nops(geo, c) > 0) {
+                            h->stream = S;
+                            rc = launch_eng_wait(h, &est->cb[c].prog, 2ull * (unsigned long long)eng_nops(geo, c));
+                        }
                 } else {
                 if (rc == RFLU_OK) rc = get_event(h, evU1(b - 1), &e);
                 if (rc == RFLU_OK && hipStreamWaitEvent(S, e, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); rc = RFLU_ERR_HIP; }

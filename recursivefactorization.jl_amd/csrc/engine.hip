@@ -207,19 +207,20 @@ __device__ __attribute__((noinline)) void eng_left_unit(const EngArgs<T>& a, int
     constexpr int SC = 8 * VW;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int LPB = a.g.W / NB;
-    const int cb0 = cb * a.g.W;
-    const int ncb_cols = min(a.g.W, a.g.n - cb0);
+    const int pb = eng_pb(a.g, cb);
+    const int cb0 = cb * a.g.Wc;
+    const int ncb_cols = min(a.g.Wc, a.g.n - cb0);
     int c0, nc, chunk0, chunk1;
     if (lk == 0) {
         c0 = cb0 + u * NB;
         nc = min(NB, ncb_cols - u * NB);
-        chunk0 = cb * LPB + u + 1;
-        chunk1 = cb * LPB + eng_leaves_of_block(a.g, cb);
+        chunk0 = c0 / NB + 1;   // (the strip is the columns of leaf c0 / NB: it owes the leaves behind it in its block column)
+        chunk1 = pb * LPB + eng_leaves_of_block(a.g, pb);
     } else {
         c0 = cb0 + u * 4 * SC;
         nc = min(4 * SC, ncb_cols - u * 4 * SC);
-        chunk0 = (cb + lk) * LPB;
-        chunk1 = chunk0 + eng_leaves_of_block(a.g, cb + lk);
+        chunk0 = (pb + lk) * LPB;
+        chunk1 = chunk0 + eng_leaves_of_block(a.g, pb + lk);
     }
     if (nc <= 0 || chunk1 <= chunk0) return;
     if (nc % VW == 0) {
@@ -241,14 +242,28 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
     __shared__ int s_sel[4];   // kind, column block, sequence, unit
     EngState* const st = a.st;
     const int tid = threadIdx.x, lane = tid & 63;
-    long long idle_since = -1;
-    int idle_rounds = 0;
     int cb_lo = 0;             // column blocks in front of this one have nothing left for the main scan (monotone)
     int fin_b = 0;             // workgroup 0: block rows [0, fin_b) have been reported final (EngArgs::rows_final)
     // x[4] = m > 0: workgroups with blockIdx % m == 1;  x[5] = k > 0: the workgroups of k XCDs (blockIdx % 8 in [1, k]);  x[6] = j > 0: of those, only blockIdx / 8 < j
     bool leaf_only = a.x[4] > 0 && (int)(blockIdx.x % (unsigned)a.x[4]) == 1;
     if (a.x[5] > 0) leaf_only = (int)(blockIdx.x & 7) >= 1 && (int)(blockIdx.x & 7) <= a.x[5] && (a.x[6] <= 0 || (int)(blockIdx.x >> 3) < a.x[6]);
 
+    // every LEAF op of the block column pb is complete: on its own column blocks (they have nothing else left) and on those of the
+    // block column to its right
+    auto leaf_ops_complete = [&](int pb) -> bool {
+        const int c0 = eng_first_cb(a.g, pb), n0 = eng_cbs_of_block(a.g, pb);
+        for (int c = c0; c < c0 + n0; ++c)
+            if ((unsigned)(eng_load(&st->cb[c].claim) >> 32) != ENG_SEQ_DONE) return false;
+        const int c1 = eng_first_cb(a.g, pb + 1), n1 = eng_cbs_of_block(a.g, pb + 1);
+        for (int c = c1; c < c1 + n1; ++c)
+            if ((int)eng_load(&st->cb[c].prog) < 2 * eng_leafn_end(a.g, c)) return false;
+        return true;
+    };
+    auto left_op_ok = [&](int cb, int lk) -> bool {
+        const int pb = eng_pb(a.g, cb);
+        if (lk == 0) return leaf_ops_complete(pb);
+        return (int)eng_load(&st->cb[eng_first_cb(a.g, pb)].bigdone) >= eng_big_users(a.g, pb);   // nobody reads this block column's L any more
+    };
     auto leaves_done = [&]() -> int {
         const unsigned long long v = eng_load(a.leaf_gate);
         return v > a.gate_base ? (int)(v - a.gate_base) : 0;
@@ -266,12 +281,13 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 for (;;) {
                     const int b = fin_b;
                     if (b >= a.g.nbp) break;
-                    bool fin = (unsigned)(eng_load(&st->cb[b].claim) >> 32) == ENG_SEQ_DONE &&
-                               (b + 1 >= a.g.ncb || (int)eng_load(&st->cb[b + 1].prog) >= 2 * eng_leafn_end(a.g, b + 1)) &&
-                               (int)eng_load(&st->cb[b].bigdone) >= eng_big_users(a.g, b) &&
-                               leaves_done() >= b * (a.g.W / NB) + eng_leaves_of_block(a.g, b);
-                    if (fin && a.g.pivot)
-                        fin = (int)eng_load(&st->cb[b].lprog) >= 1 && (int)eng_load(&st->cb[b].leftdone) >= b;
+                    const int fb = eng_first_cb(a.g, b);
+                    bool fin = leaves_done() >= b * (a.g.W / NB) + eng_leaves_of_block(a.g, b) && leaf_ops_complete(b) &&
+                               (int)eng_load(&st->cb[fb].bigdone) >= eng_big_users(a.g, b);
+                    if (fin && a.g.pivot) {
+                        const unsigned long long ld = eng_load(&st->cb[fb].leftdone);
+                        fin = (int)(ld & 0xffffffffull) >= fb && (!eng_big_waits_for_left(a.g, b) || (int)(ld >> 32) >= eng_cbs_of_block(a.g, b));
+                    }
                     if (!fin) break;
                     fin_b = b + 1;
                     if (lane == 0) {
@@ -281,10 +297,16 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     }
                 }
             }
-            for (int attempt = 0; attempt < 4 && kind == ENG_NONE; ++attempt) {
+            for (int attempt = 0; kind == ENG_NONE; ++attempt) {
                 if (eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0) { kind = ENG_EXIT; break; }
-                const int pd = leaves_done();
-                const int have = a.arrived ? (int)eng_load(a.arrived) : a.g.n;   // columns in place (host entry: they arrive while we run)
+                // what this sweep is based on: if it finds nothing, the wave sleeps on these three words until one of them moves
+                const unsigned long long seen_epoch = eng_load(&st->epoch), seen_gate = eng_load(a.leaf_gate);
+                const unsigned long long seen_arr = a.arrived ? eng_load(a.arrived) : 0ull;
+                // (the three words must have been SAMPLED before the sweep's loads are issued: loads to different channels are served
+                // in any order, and a sweep older than the epoch it is paired with sleeps through the publication it missed)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int pd = seen_gate > a.gate_base ? (int)(seen_gate - a.gate_base) : 0;
+                const int have = a.arrived ? (int)seen_arr : a.g.n;   // columns in place (host entry: they arrive while we run)
                 // ---- main units: one lane per column block -----------------------------------------------------------------
                 int best = INT_MAX;
                 int first_live = INT_MAX;
@@ -298,13 +320,13 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         if (seq != ENG_SEQ_DONE) {
                             live = true;
                             const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
-                            bool ok = o.need <= pd && (int)u < eng_units_of(o, (int)(seq & 1u), a.g.m) && min(a.g.n, (cb + 1) * a.g.W) <= have;
+                            bool ok = o.need <= pd && (int)u < eng_units_of(o, (int)(seq & 1u), a.g.m) && min(a.g.n, (cb + 1) * a.g.Wc) <= have;
                             // every x[4]-th workgroup serves the leaf-wise window only: the K = 64 operations the chain of leaves waits
                             // for find a free workgroup at once instead of queueing behind 127-us tiles of the block-column updates
                             if (leaf_only && o.type == ENG_OP_BIG) ok = false;
                             // a block column as a whole is applied with ITS interchanges complete on all its columns (engine.hpp)
                             if (ok && o.type == ENG_OP_BIG && (seq & 1u) == 0 && eng_big_waits_for_left(a.g, (int)(seq >> 1)))
-                                ok = eng_load(&st->cb[seq >> 1].lprog) >= 1;
+                                ok = (int)(eng_load(&st->cb[eng_first_cb(a.g, (int)(seq >> 1))].leftdone) >> 32) >= eng_cbs_of_block(a.g, (int)(seq >> 1));
                             if (ok) {
                                 key = a.policy ? (((o.j0 / NB) << 10) | cb) : ((1 << 24) | cb);
                                 // host entry: a block row can leave only when the panel has reached EVERY column block; with the
@@ -345,7 +367,9 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                             if ((seq & 1u) == 0) {
                                 const long long t0 = wall_clock64();
                                 const bool wl = o.type == ENG_OP_BIG && eng_big_waits_for_left(a.g, (int)(seq >> 1));
-                                while ((leaves_done() < o.need || (wl && eng_load(&st->cb[seq >> 1].lprog) < 1)) && eng_load(&st->abort) == 0) {
+                                while ((leaves_done() < o.need ||
+                                        (wl && (int)(eng_load(&st->cb[eng_first_cb(a.g, (int)(seq >> 1))].leftdone) >> 32) < eng_cbs_of_block(a.g, (int)(seq >> 1)))) &&
+                                       eng_load(&st->abort) == 0) {
                                     __builtin_amdgcn_s_sleep(16);
                                     if (wall_clock64() - t0 > 400000000LL) break;   // (the idle timeout of the others raises the flag)
                                 }
@@ -357,21 +381,15 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 // ---- deferred interchanges on the finished column blocks ---------------------------------------------------
                 if (a.g.pivot) {
                     int bestl = INT_MAX;
-                    for (int base = 0; base < a.g.nbp; base += 64) {
+                    const int nleftcb = min(a.g.ncb, eng_first_cb(a.g, a.g.nbp));   // column blocks of the served block columns
+                    for (int base = 0; base < nleftcb; base += 64) {
                         const int cb = base + lane;
                         int key = INT_MAX;
-                        if (cb < a.g.nbp) {
+                        if (cb < nleftcb) {
                             const unsigned long long w = eng_load(&st->cb[cb].lclaim);
                             const unsigned lk = (unsigned)(w >> 32), u = (unsigned)w;
                             if (lk != ENG_SEQ_DONE && eng_left_need(a.g, cb, (int)lk) <= pd && (int)u < eng_left_units<T>(a.g, cb, (int)lk)) {
-                                bool ok;
-                                if (lk == 0) {   // every LEAF op of this block column is complete: here and on the column block to the right
-                                    ok = (unsigned)(eng_load(&st->cb[cb].claim) >> 32) == ENG_SEQ_DONE &&
-                                         (cb + 1 >= a.g.ncb || (int)eng_load(&st->cb[cb + 1].prog) >= 2 * eng_leafn_end(a.g, cb + 1));
-                                } else {         // nobody reads this block column's L any more
-                                    ok = (int)eng_load(&st->cb[cb].bigdone) >= eng_big_users(a.g, cb);
-                                }
-                                if (ok) key = ((int)lk << 10) | cb;
+                                if (left_op_ok(cb, (int)lk)) key = ((int)lk << 10) | cb;
                             }
                         }
                         int mk = key;
@@ -390,11 +408,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                             const long long t0 = wall_clock64();
                             // (a later left op than the one the scan saw: its own conditions, see the scan)
                             auto left_ok = [&]() -> bool {
-                                if (leaves_done() < eng_left_need(a.g, cb, (int)lk)) return false;
-                                if (lk == 0)
-                                    return (unsigned)(eng_load(&st->cb[cb].claim) >> 32) == ENG_SEQ_DONE &&
-                                           (cb + 1 >= a.g.ncb || (int)eng_load(&st->cb[cb + 1].prog) >= 2 * eng_leafn_end(a.g, cb + 1));
-                                return (int)eng_load(&st->cb[cb].bigdone) >= eng_big_users(a.g, cb);
+                                return leaves_done() >= eng_left_need(a.g, cb, (int)lk) && left_op_ok(cb, (int)lk);
                             };
                             while (!left_ok() && eng_load(&st->abort) == 0) {
                                 __builtin_amdgcn_s_sleep(16);
@@ -404,7 +418,29 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         continue;
                     }
                 }
-                break;   // nothing is eligible right now
+                // nothing is eligible right now: wait (one lane's worth of loads per round, not a sweep) until the critical path or
+                // the engine itself has published something since this sweep began
+                {
+                    const long long t0 = wall_clock64();
+                    bool gave_up = false;
+                    int naps = 0;
+                    for (;;) {
+                        if (eng_load(&st->epoch) != seen_epoch || eng_load(a.leaf_gate) != seen_gate ||
+                            (a.arrived && eng_load(a.arrived) != seen_arr) || eng_load(&st->abort) != 0)
+                            break;
+                        naps = min(naps + 1, leaf_only ? 2 : 16);
+                        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(32);
+                        if (wall_clock64() - t0 > 400000000LL) { gave_up = true; break; }   // 4 s without any news: something upstream is stuck
+                    }
+                    if (gave_up) {
+                        if (lane == 0) {
+                            __hip_atomic_fetch_or((unsigned long long*)(a.info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            eng_store(&st->abort, 1ull);
+                        }
+                        kind = ENG_EXIT;
+                        break;
+                    }
+                }
             }
             if (lane == 0) {
                 if ((kind == ENG_MAIN || kind == ENG_LEFT) && !(a.x[1] & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -415,26 +451,10 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         const int kind = s_sel[0], cb = s_sel[1], unit = s_sel[3];
         const unsigned seq = (unsigned)s_sel[2];
         if (kind == ENG_EXIT) break;
-        if (kind == ENG_NONE) {
-            // back off: a few hundred idle workgroups polling flat out would take memory bandwidth from the working ones
-            const long long now = wall_clock64();
-            if (idle_since < 0) idle_since = now;
-            if (now - idle_since > 400000000LL) {   // 4 s without any work: something upstream is stuck
-                if (tid == 0) {
-                    __hip_atomic_fetch_or((unsigned long long*)(a.info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    eng_store(&st->abort, 1ull);
-                }
-                break;
-            }
-            idle_rounds = min(idle_rounds + 1, leaf_only ? 4 : (a.x[7] > 0 ? a.x[7] : 8));
-            for (int i = 0; i < idle_rounds; ++i) __builtin_amdgcn_s_sleep(32);
-            __syncthreads();   // s_sel is rewritten by wave 0 in the next round
-            continue;
-        }
-        idle_since = -1;
-        idle_rounds = 0;
         if (kind == ENG_MAIN) {
             const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+            if (a.trace && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == (o.j0 + o.jb + NB) / a.g.Wc)
+                a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 2 : 0)] = wall_clock64();
             if ((seq & 1u) == 0) eng_prep_unit<T>(a, o, unit, smem);
             else eng_gemm_unit<T>(a, o, unit, smem);
         } else {
@@ -462,6 +482,8 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     __hip_atomic_store(&c->prog, 2ull * (unsigned long long)(seq >> 1) + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if ((int)d == units) {
+                    if (a.trace && o.type == ENG_OP_LEAF && cb == (o.j0 + o.jb + NB) / a.g.Wc)
+                        a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                     eng_store(&c->done, 0ull);
                     const unsigned end = 2u * (unsigned)eng_nops(a.g, cb);
@@ -471,7 +493,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     if ((ns >> 1) != (seq >> 1)) {
                         for (unsigned k = seq >> 1; k < (ns >> 1); ++k)   // (the operations just completed, skipped ones included)
                             if ((int)k < eng_nbig(a.g, cb))
-                                __hip_atomic_fetch_add(&st->cb[k].bigdone, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_fetch_add(&st->cb[eng_first_cb(a.g, (int)k)].bigdone, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&c->prog, 2ull * (unsigned long long)(ns >> 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (ns >= end) {
@@ -480,6 +502,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     } else {
                         __hip_atomic_store(&c->claim, (unsigned long long)ns << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    __hip_atomic_fetch_add(&st->epoch, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
             } else {
                 const int units = eng_left_units<T>(a.g, cb, (int)seq);
@@ -491,8 +514,10 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     const int nleft = eng_nleft(a.g, cb);
                     int nk = (int)seq + 1;
                     while (nk < nleft && eng_left_units<T>(a.g, cb, nk) == 0) ++nk;
-                    for (int k = max((int)seq, 1); k < nk; ++k)   // (the left ops just completed: block columns cb + k have reached this column block)
-                        __hip_atomic_fetch_add(&st->cb[cb + k].leftdone, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    const int pbl = eng_pb(a.g, cb);
+                    for (int k = (int)seq; k < nk; ++k)   // the left ops just completed (k = 0: this block column's own interchanges; k >= 1:
+                        __hip_atomic_fetch_add(&st->cb[eng_first_cb(a.g, pbl + k)].leftdone, k == 0 ? 1ull << 32 : 1ull,   // block column pbl + k has reached it)
+                                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&c->lprog, (unsigned long long)nk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     if (nk >= nleft) {
                         __hip_atomic_store(&c->lclaim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -500,6 +525,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     } else {
                         __hip_atomic_store(&c->lclaim, (unsigned long long)nk << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    __hip_atomic_fetch_add(&st->epoch, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }

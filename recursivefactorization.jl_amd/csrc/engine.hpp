@@ -27,25 +27,29 @@ struct EngCB {
     unsigned long long ldone;
     unsigned long long prog;     // 2 * (operations completed) + (the first tile column of the current leaf window is complete): the critical-path
                                  // stream waits for prog >= 2 * op + 1 in front of a leaf's lookahead columns (the leftmost of that window)
-    unsigned long long leftdone; // column blocks to the left that have received THIS block column's interchanges (left op >= 1 of theirs)
-    unsigned long long lprog;    // left operations completed (lprog >= 1: the block column's own later interchanges have reached all its columns)
-    unsigned long long bigdone;  // column blocks that have completed BIG(this block column)
+    unsigned long long leftdone; // (first column block of a block column) own << 32 | left, see "order between the interchanges ..." below
+    unsigned long long lprog;    // left operations completed (lprog >= 1: the block column's own later interchanges have reached this column block)
+    unsigned long long bigdone;  // (first column block of a block column) column blocks that have completed BIG(this block column)
 };
 
 struct EngState {
     unsigned long long arrived;      // host entry: columns [0, arrived) of the row-major workspace are in place (written by the feeding stream)
     unsigned long long remaining;    // column-block sequences (main and left) still unfinished: the engine exits at 0
     unsigned long long abort;        // != 0: leave (timeout somewhere)
-    unsigned long long pad[5];
+    unsigned long long epoch;        // bumped whenever the engine publishes something that may make a unit eligible: an idle workgroup
+                                     // watches this word and the critical path's leaf counter instead of sweeping every claim word
+    unsigned long long pad[4];
     EngCB cb[ENG_MAX_CB];
 };
 
 // Geometry of the schedule (plain integers: host and device compute the same operation lists from it)
 struct EngGeo {
     int m, n, mn;
-    int W;          // block-column width (a multiple of 128)
+    int W;          // width of a block column = of a panel (a multiple of Wc)
+    int Wc;         // width of a COLUMN BLOCK, the unit of the dataflow (a multiple of 128 that divides W): the columns of a block column are
+                    // brought up to date in pieces of their own, so that a leaf's window does not wait for the previous leaf's last columns
     int nbp;        // the engine serves the leaves of block columns [0, nbp)
-    int ncb;        // column blocks of width W covering [0, n)
+    int ncb;        // column blocks of width Wc covering [0, n)
     int pivot;
 };
 
@@ -66,22 +70,37 @@ RFLU_HD int eng_leaves_of_block(const EngGeo& g, int b)
     const int jb = g.mn - j0 < g.W ? g.mn - j0 : g.W;
     return jb <= 0 ? 0 : (jb + NB - 1) / NB;
 }
+RFLU_HD int eng_pb(const EngGeo& g, int cb) { return (cb * g.Wc) / g.W; }          // the block column a column block belongs to
+RFLU_HD int eng_first_cb(const EngGeo& g, int b) { return b * (g.W / g.Wc); }      // first column block of block column b ...
+RFLU_HD int eng_cbs_of_block(const EngGeo& g, int b)                                // ... and how many it has
+{
+    const int first = eng_first_cb(g, b);
+    int cnt = g.ncb - first;
+    const int r = g.W / g.Wc;
+    if (cnt > r) cnt = r;
+    return cnt > 0 ? cnt : 0;
+}
 
-// operations of column block cb, in order:
-//   BIG(b),  b = 0 .. min(cb - 1, nbp) - 1 : block column b as a whole (K = W) -- block columns at least two to the left
-//   LEAF(g), g = leaves of block column cb - 1 (if that one is served): K = 64, the leaf-wise schedule's "next block column" window
-//   LEAF(g), g = leaves of block column cb itself but its last (if served): K = 64 on the columns right of the leaf's lookahead strip
+// operations of column block cb (in block column pb), in order:
+//   BIG(b),  b = 0 .. min(pb - 1, nbp) - 1 : block column b as a whole (K = W) -- block columns at least two to the left
+//   LEAF(g), g = leaves of block column pb - 1 (if that one is served): K = 64, the leaf-wise schedule's "next block column" window
+//   LEAF(g), g = leaves of block column pb itself but its last (if served): K = 64 on the columns right of the leaf's lookahead strip
 RFLU_HD int eng_nbig(const EngGeo& g, int cb)
 {
-    int v = cb - 1;
+    int v = eng_pb(g, cb) - 1;
     if (v < 0) v = 0;
     return v < g.nbp ? v : g.nbp;
 }
-RFLU_HD int eng_nleafn(const EngGeo& g, int cb) { return (cb >= 1 && cb - 1 < g.nbp) ? eng_leaves_of_block(g, cb - 1) : 0; }
+RFLU_HD int eng_nleafn(const EngGeo& g, int cb)
+{
+    const int pb = eng_pb(g, cb);
+    return (pb >= 1 && pb - 1 < g.nbp) ? eng_leaves_of_block(g, pb - 1) : 0;
+}
 RFLU_HD int eng_nleafo(const EngGeo& g, int cb)
 {
-    if (cb >= g.nbp) return 0;
-    const int nl = eng_leaves_of_block(g, cb);
+    const int pb = eng_pb(g, cb);
+    if (pb >= g.nbp) return 0;
+    const int nl = eng_leaves_of_block(g, pb);
     return nl > 1 ? nl - 1 : 0;
 }
 RFLU_HD int eng_nops(const EngGeo& g, int cb) { return eng_nbig(g, cb) + eng_nleafn(g, cb) + eng_nleafo(g, cb); }
@@ -90,8 +109,9 @@ RFLU_HD EngOp eng_op(const EngGeo& g, int cb, int k)
 {
     EngOp o;
     const int LPB = g.W / NB;
-    const int cb0 = cb * g.W;
-    const int cb_end = cb0 + g.W < g.n ? cb0 + g.W : g.n;
+    const int pb = eng_pb(g, cb);
+    const int cb0 = cb * g.Wc;
+    const int cb_end = cb0 + g.Wc < g.n ? cb0 + g.Wc : g.n;
     const int nbig = eng_nbig(g, cb);
     if (k < nbig) {
         o.type = ENG_OP_BIG;
@@ -106,49 +126,51 @@ RFLU_HD EngOp eng_op(const EngGeo& g, int cb, int k)
     }
     const int nln = eng_nleafn(g, cb);
     int leaf;
-    if (k - nbig < nln) leaf = (cb - 1) * LPB + (k - nbig);
-    else leaf = cb * LPB + (k - nbig - nln);
+    if (k - nbig < nln) leaf = (pb - 1) * LPB + (k - nbig);
+    else leaf = pb * LPB + (k - nbig - nln);
     o.type = ENG_OP_LEAF;
     o.j0 = leaf * NB;
     o.jb = g.mn - o.j0 < NB ? g.mn - o.j0 : NB;
     const int la1 = o.j0 + o.jb + NB;   // the leaf's lookahead strip [j0 + jb, la1) is the critical-path stream's own business
     o.c_lo = la1 > cb0 ? la1 : cb0;
-    o.nc = cb_end - o.c_lo;
+    o.nc = cb_end - o.c_lo;             // (<= 0 for the column blocks left of the strip: the operation completes by itself)
     o.chunk0 = leaf;
     o.chunk1 = leaf + 1;
     o.need = leaf + 1;
     return o;
 }
 
-// index of LEAF(leaf) in column block cb's operation list (cb = the leaf's own block column or the one right of it)
+// index of LEAF(leaf) in column block cb's operation list (cb in the leaf's own block column or the one right of it)
 RFLU_HD int eng_leaf_op_index(const EngGeo& g, int cb, int leaf)
 {
     const int LPB = g.W / NB;
     const int lb = leaf / LPB;
-    if (lb == cb - 1) return eng_nbig(g, cb) + (leaf - lb * LPB);
-    return eng_nbig(g, cb) + eng_nleafn(g, cb) + (leaf - cb * LPB);
+    if (lb == eng_pb(g, cb) - 1) return eng_nbig(g, cb) + (leaf - lb * LPB);
+    return eng_nbig(g, cb) + eng_nleafn(g, cb) + (leaf - lb * LPB);
 }
 
-// ---- deferred interchanges on finished column blocks (cb < nbp): left op 0 = the later leaves of the block column itself on the
-// columns of its earlier leaves (one unit per 64-column strip), left op i >= 1 = block column cb + i as a whole
+// ---- deferred interchanges on finished column blocks (block column pb < nbp): left op 0 = the later leaves of the block column
+// itself on the columns of its earlier leaves (one unit per 64-column strip of the column block), left op i >= 1 = block column
+// pb + i as a whole
 RFLU_HD int eng_nleft(const EngGeo& g, int cb)
 {
-    if (!g.pivot || cb >= g.nbp) return 0;
-    return 1 + (g.nbp - 1 - cb);
+    const int pb = eng_pb(g, cb);
+    if (!g.pivot || pb >= g.nbp) return 0;
+    return 1 + (g.nbp - 1 - pb);
 }
 RFLU_HD int eng_left_need(const EngGeo& g, int cb, int lk)
 {
-    const int b = cb + lk;
+    const int b = eng_pb(g, cb) + lk;
     return b * (g.W / NB) + eng_leaves_of_block(g, b);
 }
 template <typename T>
 RFLU_HD int eng_left_units(const EngGeo& g, int cb, int lk)
 {
-    const int cb0 = cb * g.W;
-    const int nc = (cb0 + g.W < g.n ? cb0 + g.W : g.n) - cb0;
+    const int cb0 = cb * g.Wc;
+    const int nc = (cb0 + g.Wc < g.n ? cb0 + g.Wc : g.n) - cb0;
     if (lk == 0) {
-        const int nl = eng_leaves_of_block(g, cb);
-        return nl > 1 ? nl - 1 : 0;
+        if (eng_leaves_of_block(g, eng_pb(g, cb)) <= 1) return 0;
+        return (nc + NB - 1) / NB;   // (a strip whose leaf is the block column's last has nothing to receive: its unit returns at once)
     }
     constexpr int SC4 = 4 * 8 * (16 / (int)sizeof(T));   // four wave strips of one 128-byte line per row
     return (nc + SC4 - 1) / SC4;
@@ -164,20 +186,23 @@ RFLU_HD int eng_units_of(const EngOp& o, int stage, int m)
 }
 
 // ---- order between the interchanges and the readers of a panel ------------------------------------------------------------------
-// The leaves of block column b are applied one by one (LEAF ops on column blocks b and b + 1) with the rows of L in the order of
-// THAT leaf; the block column as a whole (BIG(b), column blocks b + 2 ...) needs L with all of the block column's interchanges
-// applied (left op 0 of column block b), and the interchanges of later block columns may permute L(b) only when nobody reads it
-// any more:
-//   left op 0 of b     after  every LEAF op of block column b is complete (column blocks b and b + 1)
-//   BIG(b) anywhere    after  left op 0 of b                                  (lprog[b] >= 1)
+// The leaves of block column b are applied one by one (LEAF ops on the column blocks of block columns b and b + 1) with the rows of L
+// in the order of THAT leaf; the block column as a whole (BIG(b), block columns b + 2 ...) needs L with all of the block column's
+// interchanges applied (left op 0 of every column block of b), and the interchanges of later block columns may permute L(b) only
+// when nobody reads it any more:
+//   left op 0 of b     after  every LEAF op of block column b is complete (column blocks of b and of b + 1)
+//   BIG(b) anywhere    after  left op 0 on every column block of b              (own count of b == eng_cbs_of_block(b))
 //   left op >= 1 of b  after  BIG(b) is complete on every column block that has it   (bigdone[b] == eng_big_users(b))
+// The per-block-column counters live in the entry of the block column's FIRST column block: `bigdone`, and `leftdone` = (column
+// blocks of this block column whose left op 0 is complete) << 32 | (column blocks to the left that have received this block
+// column's interchanges).
 RFLU_HD bool eng_big_waits_for_left(const EngGeo& g, int b) { return g.pivot && eng_leaves_of_block(g, b) > 1; }
 RFLU_HD int eng_big_users(const EngGeo& g, int b)
 {
-    const int v = g.ncb - (b + 2);
+    const int v = g.ncb - eng_first_cb(g, b + 2);
     return (b < g.nbp && v > 0) ? v : 0;
 }
-RFLU_HD int eng_leafn_end(const EngGeo& g, int cb) { return eng_nbig(g, cb) + eng_nleafn(g, cb); }   // ops of cb up to its LEAF ops of block column cb - 1
+RFLU_HD int eng_leafn_end(const EngGeo& g, int cb) { return eng_nbig(g, cb) + eng_nleafn(g, cb); }   // ops of cb up to its LEAF ops of the block column in front
 
 template <typename T>
 struct EngArgs {
@@ -198,6 +223,7 @@ struct EngArgs {
     const unsigned long long* arrived;     // columns [0, *arrived) of R are in place (nullptr: all of them)
     unsigned long long* rows_final;        // host-visible word: rows [0, *rows_final) of the factors are final (nullptr: nobody asks)
     int gemm_flags;
+    long long* trace;   // measurement (RFLU_ENGINE_TRACE): per leaf g four wall-clock stamps of LEAF(g) on the column block of its first columns
     int x[8];       // experiment switches (Tune::engine_x)
 };
 

@@ -321,8 +321,19 @@ static int panel_flags_status(Handle* h)
                   "(set RFLU_PANEL_LOCAL=0 to use the placement-independent kernel)");
         return RFLU_ERR_PLACEMENT;
     }
+    if (f != 0 && h->eng_state && env_str("RFLU_ENGINE_DUMP")) {   // debugging: where the engine and the chain stood when somebody gave up
+        EngState es;
+        unsigned long long gate[3] = {0, 0, 0};
+        (void)hipMemcpy(&es, h->eng_state, offsetof(EngState, cb) + 16 * sizeof(EngCB), hipMemcpyDeviceToHost);
+        for (int i = 0; i < 3; ++i) (void)hipMemcpy(&gate[i], h->gate_ptr[i], 8, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[rflu] engine dump: flags 0x%llx gates %llu %llu %llu arrived %llu remaining %llu abort %llu epoch %llu\n", (unsigned long long)f, gate[0], gate[1], gate[2],
+                es.arrived, es.remaining, es.abort, es.epoch);
+        for (int c = 0; c < 16; ++c)
+            fprintf(stderr, "   cb %2d: claim %llx done %llx lclaim %llx ldone %llu prog %llu leftdone %llx lprog %llu bigdone %llu\n", c, es.cb[c].claim, es.cb[c].done, es.cb[c].lclaim,
+                    es.cb[c].ldone, es.cb[c].prog, es.cb[c].leftdone, es.cb[c].lprog, es.cb[c].bigdone);
+    }
     if (f != 0) {
-        set_error("cooperative panel kernel timed out waiting for a peer workgroup");
+        set_error("cooperative panel kernel timed out waiting for a peer workgroup (flags 0x%llx: 1 = a leaf / gate, 16 = the engine idle, 32 = a wait for the engine, 64 = the XCD-local leaf)", (unsigned long long)f);
         return RFLU_ERR_TIMEOUT;
     }
     return RFLU_OK;

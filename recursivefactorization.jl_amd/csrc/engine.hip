@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     }
                     if (gave_up) {
                         if (lane == 0) {
-                            __hip_atomic_fetch_or((unsigned long long*)(a.info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_or((unsigned long long*)(a.info + 1), 17ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             eng_store(&st->abort, 1ull);
                         }
                         kind = ENG_EXIT;
@@ -563,7 +563,7 @@ __global__ void eng_wait_kernel(const unsigned long long* flag, unsigned long lo
         if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // somebody has already given up
         __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > 400000000LL) {   // 4 s: the engine is stuck (or gone): raise the timeout flag, release everybody
-            __hip_atomic_fetch_or((unsigned long long*)(info + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_or((unsigned long long*)(info + 1), 33ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(abort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }

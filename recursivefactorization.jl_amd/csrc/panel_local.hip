@@ -219,7 +219,7 @@ __device__ __forceinline__ bool x_w0_exchange(XLds<T>* sh, u64* scratch, int64_t
     const bool dead = __any(timed_out);
     if (dead) {
         gp = POS_DEAD;
-        if (lane == 0) __hip_atomic_fetch_or((u64*)(info + 1), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_or((u64*)(info + 1), (u64)65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const T sc = readlane_val(xinv, wl);   // 1 / pivot (1 when the pivot is exactly zero or there is no candidate)
     const T p1 = readlane_val(pc, (c1 + 1) & 63), p2 = readlane_val(pc, (c1 + 2) & 63);   // P_c[c1+1], P_c[c1+2]

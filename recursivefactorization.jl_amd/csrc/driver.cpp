@@ -72,6 +72,8 @@ void Tune::load_env()
     ld_pad = (ld_pad / 16) * 16;
     env_get("RFLU_TRSV_MAX_RHS", trsv_max_rhs);
     env_get("RFLU_TRSM_CHAIN_MAX_RHS", trsm_chain_max_rhs);
+    env_get("RFLU_TRSM_CHAIN_SPLIT", trsm_chain_split);
+    env_get("RFLU_TRSM_CHAIN_CACHED", trsm_chain_cached);
     env_get("RFLU_QUEUE_CHECK", queue_check);
     env_flag("RFLU_QUEUE_TRACE", queue_trace);
     env_flag("RFLU_SPLIT_ALL", split_all);

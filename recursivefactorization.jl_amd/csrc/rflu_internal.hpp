@@ -72,6 +72,9 @@ struct Tune {
     int64_t ld_pad = 0;                // RFLU_LD_PAD
     int64_t trsv_max_rhs = 32;         // RFLU_TRSV_MAX_RHS
     int64_t trsm_chain_max_rhs = 320;  // RFLU_TRSM_CHAIN_MAX_RHS: up to this many right-hand sides the cooperative solve in passes of 64 (MFMA)
+    int trsm_chain_cached = 1;         // RFLU_TRSM_CHAIN_CACHED=0: every workgroup fetches x_d with cache-bypassing loads (trsv.hip)
+    int trsm_chain_split = 2;          // RFLU_TRSM_CHAIN_SPLIT: a pass of 64 right-hand sides as 0 = one chain of 64 columns, 1 = four of 16 in runs of two blocks,
+                                       // 2 = two chains of 32 side by side (trsv.hip; n = 16384, 64 columns: 5.55 / 5.41 / 4.81 ms)
     // streams and queues
     int queue_check = 1;               // RFLU_QUEUE_CHECK
     int queue_trace = 0;               // RFLU_QUEUE_TRACE
@@ -198,6 +201,8 @@ struct Handle {
     int panel_local_maxg = 64;
     int panel_xcc = 0;
     int trsv_max_wgs = 0;        // same for the cooperative solve kernels (asked on first use)
+    int trsm32_per_cu = 0;
+    int trsm16_per_cu = 0;       // workgroups of the 16-column block solve a CU holds (trsv.hip: chains side by side)
     int panel_max_wgs = 0;       // how many workgroups of the cooperative panel kernels the device holds at once (occupancy query)
     bool coop_launch = false;    // RFLU_COOP_LAUNCH=1: hipLaunchCooperativeKernel (launch-time residency check, +15-19 us each)
     bool la_attr_set[2] = {false, false};     // dynamic-LDS opt-in of leaf_la_kernel (f64, f32)

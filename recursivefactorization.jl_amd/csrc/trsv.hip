@@ -14,6 +14,7 @@
 //     (each 64x64 block of the triangle read exactly once) trails behind it.
 // Roofline: HBM -- algorithmic bytes = sizeof(T) * n^2 / 2 per triangle; latency floor = n/64 stages x (one cross-workgroup
 // hop + two block products).  Up to TV_NR right-hand sides ride along in one pass.
+#include <cstdlib>
 #include "rflu_internal.hpp"
 
 namespace rflu {
@@ -133,6 +134,33 @@ __device__ __forceinline__ bool tv_load(__amdgpu_buffer_rsrc_t r, unsigned off, 
 __device__ __forceinline__ bool tv_load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, float& v)
 {
     const tv_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, TV_AUX_SC1);
+    v = __uint_as_float(x[0]);
+    return x[1] == tag && x[3] == tag;
+}
+// raw granule now, tag check later (a fetch issued a stage ahead, trsm_chain_kernel)
+__device__ __forceinline__ tv_u4 tv_load_raw(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, TV_AUX_SC1); }
+__device__ __forceinline__ bool tv_decode(const tv_u4& x, unsigned tag, double& v)
+{
+    v = __longlong_as_double((long long)(((unsigned long long)x[0] << 32) | (unsigned long long)x[2]));
+    return x[1] == tag && x[3] == tag;
+}
+__device__ __forceinline__ bool tv_decode(const tv_u4& x, unsigned tag, float& v)
+{
+    v = __uint_as_float(x[0]);
+    return x[1] == tag && x[3] == tag;
+}
+// The same through the caches: for the many workgroups that fetch a block everybody fetches (the first one of an XCD brings the line into
+// that XCD's L2, the others hit it there).  A line that was cached before its granule was written shows the old tag: the caller falls
+// back to tv_load.
+__device__ __forceinline__ bool tv_load_cached(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, double& v)
+{
+    const tv_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    v = __longlong_as_double((long long)(((unsigned long long)x[0] << 32) | (unsigned long long)x[2]));
+    return x[1] == tag && x[3] == tag;
+}
+__device__ __forceinline__ bool tv_load_cached(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned tag, float& v)
+{
+    const tv_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
     v = __uint_as_float(x[0]);
     return x[1] == tag && x[3] == tag;
 }
@@ -363,7 +391,11 @@ __global__ void __launch_bounds__(TV_THREADS) trsv_chain_kernel(int n, int nrhs,
 // v_mfma_f64_16x16x4 of 64 clocks each per wave) + ~5 us from the previous owner's first granule store to x_d in this workgroup's LDS
 // (64 KB of granules through the memory side) + the owner's own previous stage (its block's update and y: two more products).
 constexpr int TC_NR = 64;                 // right-hand sides per pass
-constexpr int TC_XLD = TC_NR + 16;        // LDS row pitch of x_d ([k][column]; == 16 mod 32 doubles: conflict-free fragment reads)
+// Round 5, second step: the columns of a pass are independent, so a pass runs as `chains` chains of NRC = 16 columns side by side
+// (blockIdx / G = chain): a stage then moves 16 KB of granules and one MFMA fragment per wave instead of 64 KB and four, and the factor
+// is read once per chain (4 GiB instead of 1 per triangle at n = 16384: still under the stage time).  n = 16384, 64 right-hand sides:
+// 5.9 -> see DESIGN.md section 7.
+constexpr int tc_xld(int nrc) { return nrc % 32 == 16 ? nrc : (nrc + 16) % 32 == 16 ? nrc + 16 : nrc + 32; }   // LDS row pitch of x_d ([k][column]; == 16 mod 32 doubles: conflict-free fragment reads)
 
 template <typename T>
 struct TcMfma;
@@ -395,232 +427,372 @@ __device__ __forceinline__ void tc_load_a(const T* __restrict__ M, int64_t ldm, 
     }
 }
 
-// acc += A * xs   (xs: [64][TC_XLD] in LDS)
-template <typename T>
-__device__ __forceinline__ void tc_mma(const T (&a)[16], const T* xs, int lane, typename TcMfma<T>::acc_t (&acc)[4])
+// acc += A * xs   (xs: [64][XLD] in LDS)
+template <typename T, int FR, int XLD>
+__device__ __forceinline__ void tc_mma(const T (&a)[16], const T* xs, int lane, typename TcMfma<T>::acc_t (&acc)[FR])
 {
     const int fi = lane & 15, fk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-        const T* xr = xs + (4 * kk + fk) * TC_XLD + fi;
+        const T* xr = xs + (4 * kk + fk) * XLD + fi;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = TcMfma<T>::run(a[kk], xr[16 * t], acc[t]);
+        for (int t = 0; t < FR; ++t) acc[t] = TcMfma<T>::run(a[kk], xr[16 * t], acc[t]);
     }
 }
 
-template <typename T, bool UPPER>
-__global__ void __launch_bounds__(TV_THREADS) trsm_chain_kernel(int n, int nrhs, const T* __restrict__ R, int64_t ld,
+#ifdef RFLU_TC_TRACE
+__device__ long long tc_trace_pub[2][1024];      // [triangle][block]: wall clock when the block's x was published (chain 0)
+__device__ long long tc_trace_wg[2][1024][6];
+__device__ long long tc_trace_own[2][1024][4];   // [triangle][block]: its owner at the top of the stage that solves it, x_d landed, product done, loop end of that stage
+#define TC_STAMP_OWN(r, i) do { if (chain == 0 && tid == 0 && (r) >= 0 && (r) < 1024) tc_trace_own[UPPER ? 1 : 0][r][i] = wall_clock64(); } while (0)    // [triangle][stage][point]: one bystander workgroup (w = 7 of chain 0)
+#define TC_STAMP_PUB(r) do { if (chain == 0 && tid == 0 && (r) < 1024) tc_trace_pub[UPPER ? 1 : 0][r] = wall_clock64(); } while (0)
+#define TC_STAMP_WG(s, i) do { if (chain == 0 && w == 7 && tid == 0 && (s) < 1024) tc_trace_wg[UPPER ? 1 : 0][s][i] = wall_clock64(); } while (0)
+#else
+#define TC_STAMP_PUB(r) do { } while (0)
+#define TC_STAMP_WG(s, i) do { } while (0)
+#define TC_STAMP_OWN(r, i) do { } while (0)
+#endif
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also waits for every outstanding global access of the wave: the
+// acknowledgement of the write-through granule / result stores just issued (1-2 us) and the loads issued AHEAD on purpose (the next
+// stage's -T block, the next x) -- which is what made a stage cost 9-10 us whatever it moved.  Everything the barriers of
+// trsm_chain_kernel order goes through LDS; global data is either private to a thread (a C tile: the same thread reads what it wrote)
+// or carries tags.
+__device__ __forceinline__ void tc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T, bool UPPER, int NRC, int RUN>
+__global__ void __launch_bounds__(TV_THREADS) trsm_chain_kernel(int n, int nrhs_all, const T* __restrict__ R, int64_t ld,
                                                                 const T* __restrict__ Dinv, const T* __restrict__ Msub, T* X, int64_t ldx,
-                                                                void* xchg, unsigned xchg_bytes, unsigned tag, int64_t* err)
+                                                                void* xchg_all, unsigned xchg_bytes, unsigned tag, int64_t* err, int chains, int cached_fetch)
 {
     typedef typename TcMfma<T>::acc_t acc_t;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xchg, 0, xchg_bytes, 0x00020000);
+    constexpr int FR = NRC / 16;          // accumulator fragments per wave (16 rows x NRC columns)
+    constexpr int TC_XLD = tc_xld(NRC);
+    constexpr int GP = NRC / 4;           // granules of x_d a thread fetches (row tid >> 2)
+    const int G = (int)gridDim.x / chains, w = (int)blockIdx.x % G, chain = (int)blockIdx.x / G;
+    X += chain * NRC;
+    const int nrhs = min(NRC, nrhs_all - chain * NRC);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(xchg_all) + (size_t)chain * xchg_bytes, 0, xchg_bytes, 0x00020000);
     __shared__ T xs[2][NB * TC_XLD];   // x_d by parity of the stage
     __shared__ T ys[NB * TC_XLD];      // the block two stages ahead, staged as a B operand for y = inv(D) * b
     __shared__ int s_dead;
+    __shared__ int s_ok[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15;
     const int nb = (n + NB - 1) / NB;
-    const int G = gridDim.x, w = blockIdx.x;
     const int dir = UPPER ? -1 : 1;
     const int d0 = UPPER ? nb - 1 : 0;
     if (tid == 0) s_dead = 0;
     auto rows_of = [&](int r) { return min(NB, n - r * NB); };
     // C-layout access to block r of X: row 16w + crow(lane, q), column 16t + fi
-    auto load_c = [&](int r, acc_t (&c)[4]) {
+    auto load_c = [&](int r, acc_t (&c)[FR]) {
         const int rn = rows_of(r);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = wave * 16 + TcMfma<T>::crow(lane, q);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < FR; ++t) {
                 const int col = 16 * t + fi;
                 c[t][q] = (row < rn && col < nrhs) ? X[(int64_t)(r * NB + row) * ldx + col] : T(0);
             }
         }
     };
-    auto store_c = [&](int r, const acc_t (&c)[4]) {
+    auto store_c = [&](int r, const acc_t (&c)[FR]) {
         const int rn = rows_of(r);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = wave * 16 + TcMfma<T>::crow(lane, q);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < FR; ++t) {
                 const int col = 16 * t + fi;
                 if (row < rn && col < nrhs) X[(int64_t)(r * NB + row) * ldx + col] = c[t][q];
             }
         }
     };
-    auto stage_c = [&](T* dst, const acc_t (&c)[4]) {   // C layout -> [row][TC_XLD] in LDS
-        // (volatile: one ds_write per element.  hipcc 7.2 paired the Float32 writes of this loop into ds_write2_b32 with a wrong first
-        //  offset -- column 4 instead of 16 for the second fragment -- and a quarter of the staged block kept its old contents)
-        volatile T* vd = dst;
+    auto stage_c = [&](T* dst, const acc_t (&c)[FR]) {   // C layout -> [row][TC_XLD] in LDS
+        // (one ds_write per element, kept apart by compiler barriers: hipcc 7.2 paired the Float32 writes of this loop into ds_write2_b32
+        //  with a wrong first offset -- column 4 instead of 16 for the second fragment -- and a quarter of the staged block kept its old
+        //  contents.  Not `volatile`: a volatile LDS write is preceded by s_waitcnt vmcnt(0), i.e. by a wait for the acknowledgement of
+        //  every store and the arrival of every load issued ahead -- 2 us, four times per stage)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = wave * 16 + TcMfma<T>::crow(lane, q);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) vd[row * TC_XLD + 16 * t + fi] = c[t][q];
+            for (int t = 0; t < FR; ++t) {
+                dst[row * TC_XLD + 16 * t + fi] = c[t][q];
+                asm volatile("" ::: "memory");
+            }
         }
     };
     // x_r = c: granules for the other workgroups, the final values into X, and this workgroup's own copy for the stage that uses it
-    auto publish = [&](int r, const acc_t (&c)[4], T* own) {
+    auto publish = [&](int r, const acc_t (&c)[FR], T* own) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = wave * 16 + TcMfma<T>::crow(lane, q);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                tv_store(rx, (unsigned)((r * NB + row) * TC_NR + 16 * t + fi) * 16u, tag, c[t][q]);
+            for (int t = 0; t < FR; ++t)
+                tv_store(rx, (unsigned)((r * NB + row) * NRC + 16 * t + fi) * 16u, tag, c[t][q]);
         }
         stage_c(own, c);
         store_c(r, c);
     };
-    auto owner_of = [&](int r) { return r % G; };
+    // Ownership in RUNS: blocks q = RUN k .. RUN k + RUN - 1 (q counts in solve order) belong to workgroup k mod G.  Inside a run the next
+    // x needs no hop -- the owner has x_d in its LDS when it publishes it -- so a chain of nb stages pays nb / RUN hops (a hop: 5-8 us from
+    // the publish to the block in the next owner's LDS, against 0.5-2 us per product).
+    auto qof = [&](int r) { return UPPER ? nb - 1 - r : r; };
+    auto rof = [&](int q) { return UPPER ? nb - 1 - q : q; };
+    auto owner_of = [&](int r) { return (qof(r) / RUN) % G; };
     // next owned block at or beyond block r in solve order (-1: none)
     auto owned_from = [&](int r) -> int {
-        if (!UPPER) {
-            if (r >= nb) return -1;
-            const int q = r + ((w - r) % G + G) % G;
-            return q < nb ? q : -1;
-        }
-        if (r < 0) return -1;
-        const int q = r - ((r - w) % G + G) % G;
-        return q >= 0 ? q : -1;
+        if (r < 0 || r >= nb) return -1;
+        const int q = qof(r), run = q / RUN;
+        const int delta = ((w - run) % G + G) % G;
+        const int q2 = delta == 0 ? q : (run + delta) * RUN;
+        return q2 < nb ? rof(q2) : -1;
     };
     int ns = owned_from(d0);             // the block this workgroup solves next
-    const bool single = nb <= G;         // one block per workgroup: it stays in registers from the first stage to its solution
-    acc_t yv[4];                         // y of that block (valid from the stage before it is solved)
-    acc_t cacc[4];                       // single: the block itself, minus everything subtracted so far
+    // the blocks of the run ns belongs to stay in registers from the moment the run becomes current to their solution (every earlier
+    // x_d is subtracted there); runs further on are updated in X
+    acc_t racc[RUN][FR];
+    int cur_first = -1;                  // first block (solve order) of the run in registers
+    auto run_index = [&](int r) -> int { // position of block r in the current run, -1: not in it
+        if (cur_first < 0 || r < 0) return -1;
+        const int k = qof(r) - qof(cur_first);
+        return (k >= 0 && k < RUN && owner_of(r) == w) ? k : -1;
+    };
+    auto load_run = [&]() {
+        cur_first = ns;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) yv[t] = cacc[t] = acc_t{T(0), T(0), T(0), T(0)};
-    T mcrit[16], dcrit[16];              // A fragments of -M_ns and of inv(D_ns): requested when ns changes, a stage or more ahead of their use
+        for (int k = 0; k < RUN; ++k) {
+#pragma unroll
+            for (int t = 0; t < FR; ++t) racc[k][t] = acc_t{T(0), T(0), T(0), T(0)};
+            const int r = ns < 0 ? -1 : ns + dir * k;
+            if (r >= 0 && r < nb && qof(r) / RUN == qof(ns) / RUN) load_c(r, racc[k]);
+        }
+    };
+    acc_t yv[FR];                        // y of block ns (valid from the stage before it is solved)
+#pragma unroll
+    for (int t = 0; t < FR; ++t) yv[t] = acc_t{T(0), T(0), T(0), T(0)};
+    // A fragments of -M and of inv(D) for block ns and (RUN == 2) for the block behind it in its run: requested when a run becomes
+    // current, a stage or more ahead of their use
+    T mcrit[16], dcrit[16], mcritB[16], dcritB[16];
     auto load_crit = [&]() {
         if (ns >= 0) {
             tc_load_a<T>(Msub + (size_t)ns * NB * NB, NB, NB, NB, wave, lane, mcrit, true);
             tc_load_a<T>(Dinv + (size_t)ns * NB * NB, NB, NB, NB, wave, lane, dcrit, false);
+            if constexpr (RUN == 2) {
+                const int r2 = ns + dir;
+                if (r2 >= 0 && r2 < nb && qof(r2) / RUN == qof(ns) / RUN) {
+                    tc_load_a<T>(Msub + (size_t)r2 * NB * NB, NB, NB, NB, wave, lane, mcritB, true);
+                    tc_load_a<T>(Dinv + (size_t)r2 * NB * NB, NB, NB, NB, wave, lane, dcritB, false);
+                }
+            }
+        }
+    };
+    // ns has been solved: on to the next block of the run (its fragments are here) or to the next run (requested now)
+    auto advance = [&]() {
+        const int prev = ns;
+        ns = owned_from(ns + dir);
+        if (RUN == 2 && ns >= 0 && qof(ns) / RUN == qof(prev) / RUN) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { mcrit[i] = mcritB[i]; dcrit[i] = dcritB[i]; }
+        } else {
+            load_crit();
+            load_run();
         }
     };
     load_crit();
-    __syncthreads();
-    // y = inv(D_r) * b_r with b_r read from X through the LDS staging (b_r is complete but for the stage that uses M)
-    auto make_y = [&](int r, const T (&dv)[16], acc_t (&y)[4]) {
-        acc_t c[4];
-        load_c(r, c);
+    load_run();
+    tc_barrier();
+    // y = inv(D) * c for a block held in registers (C layout), through the LDS staging
+    auto make_y = [&](const acc_t (&c)[FR], const T (&dv)[16], acc_t (&y)[FR]) {
         stage_c(ys, c);
-        __syncthreads();
+        tc_barrier();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) y[t] = acc_t{T(0), T(0), T(0), T(0)};
-        tc_mma<T>(dv, ys, lane, y);
-        __syncthreads();   // ys may be rewritten
+        for (int t = 0; t < FR; ++t) y[t] = acc_t{T(0), T(0), T(0), T(0)};
+        tc_mma<T, FR, TC_XLD>(dv, ys, lane, y);
+        tc_barrier();   // ys may be rewritten
     };
     // prologue: the first block is solved outright, the second one has its y before the first stage
     if (ns == d0) {
-        acc_t x0[4];
-        make_y(d0, dcrit, x0);
+        acc_t x0[FR];
+        make_y(racc[0], dcrit, x0);
         publish(d0, x0, xs[0]);
-        ns = owned_from(d0 + dir * G);
-        load_crit();
+        advance();
     }
-    if (ns == d0 + dir) make_y(ns, dcrit, yv);
-    else if (single && ns >= 0) load_c(ns, cacc);
-    // -T of the first stage's nearest trailing block (requested a stage ahead from here on)
-    T tnear[16];
-    {
-        const int rn = owned_from(d0 + 2 * dir);
-        if (rn >= 0) tc_load_a<T>(R + (int64_t)rn * NB * ld + d0 * NB, ld, rows_of(rn), min(NB, n - d0 * NB), wave, lane, tnear, true);
+    if (ns == d0 + dir) {
+        const int k = run_index(ns);   // (workgroup-uniform)
+#pragma unroll
+        for (int kk = 0; kk < RUN; ++kk)
+            if (k == kk) make_y(racc[kk], dcrit, yv);
     }
-    __syncthreads();
+    // -T of the blocks of the current run for the stage that comes next, requested a stage ahead: tnear[k] holds -T(tn_blk[k], tn_col)
+    T tnear[RUN][16];
+    int tn_blk[RUN], tn_col = -1;
+    auto request_t = [&](int col, int beyond_q) {   // for the current run's blocks behind position beyond_q (solve order)
+        tn_col = col;
+#pragma unroll
+        for (int k = 0; k < RUN; ++k) {
+            const int r = cur_first < 0 ? -1 : cur_first + dir * k;
+            tn_blk[k] = -1;
+            if (r >= 0 && r < nb && qof(r) / RUN == qof(cur_first) / RUN && qof(r) > beyond_q) {
+                tc_load_a<T>(R + (int64_t)r * NB * ld + col * NB, ld, rows_of(r), min(NB, n - col * NB), wave, lane, tnear[k], true);
+                tn_blk[k] = r;
+            }
+        }
+    };
+    request_t(d0, qof(d0 + dir));
+    tc_barrier();
 
+    // Every workgroup handles every stage, and a stage handled strictly in sequence costs {wait, fetch latency, LDS, barrier, product(s),
+    // barrier}: that sum, not the hop to the next owner, set the pace (runs of two blocks changed nothing by themselves).  So the fetch
+    // of x_(d+1) is ISSUED during stage d, right after x_d has landed, and looked at when stage d + 1 begins: a workgroup that is behind
+    // the front finds the block complete and never waits for memory.  (16-column chains only: the raw granules wait in registers.)
+    constexpr bool PREFETCH = NRC <= 16;
+    tv_u4 praw[PREFETCH ? GP : 1];
+    bool pre_valid = false;
     for (int s = 0; s + 1 < nb; ++s) {   // the last block's x has nobody to go to
         const int d = d0 + dir * s, dnext = d + dir;
         T* xd = xs[s & 1];
         if (owned_from(dnext) < 0) break;   // nothing left for this workgroup (workgroup-uniform)
+        TC_STAMP_WG(s, 0);
+        if (ns == dnext) TC_STAMP_OWN(ns, 0);
         // ---- x_d
         if (w != owner_of(d)) {
             const bool urgent = ns == dnext || ns == dnext + dir;
-            // thread -> row k = tid >> 2, columns (tid & 3) * 16 + j: all 16 granules requested, the missing ones again
-            const int k = tid >> 2, cb = (tid & 3) * 16;
-            T v[16];
-            unsigned miss = 0xffffu;
+            // thread -> row k = tid >> 2, columns (tid & 3) * GP + j: all GP granules requested, the missing ones again
+            const int k = tid >> 2, cb = (tid & 3) * GP;
+            T v[GP];
+            unsigned miss = (1u << GP) - 1u;
             int spins = 0;
             bool timed_out = false;
-            const unsigned goff = (unsigned)((d * NB + k) * TC_NR + cb) * 16u;
-            if (!urgent) {
+            const unsigned goff = (unsigned)((d * NB + k) * NRC + cb) * 16u;
+            if constexpr (PREFETCH) {
+                if (pre_valid) {
+                    miss = 0;
+#pragma unroll
+                    for (int j = 0; j < GP; ++j) miss |= tv_decode(praw[j], tag, v[j]) ? 0u : (1u << j);
+                }
+            }
+            // (workgroup-uniform decision: the waiting below has a barrier in it)
+            bool all_here = false;
+            if (PREFETCH && pre_valid) {
+                const bool wave_ok = __ballot(miss == 0) == ~0ull;
+                if (lane == 0) s_ok[wave] = wave_ok ? 1 : 0;
+                tc_barrier();
+                all_here = (s_ok[0] & s_ok[1] & s_ok[2] & s_ok[3]) != 0;
+            }
+            if (!urgent && !all_here) {
                 // a workgroup whose turn is not near waits for ONE granule of x_d with one lane, at leisure, and fetches the block
                 // when that one is there: 250 workgroups sweeping 64 KB per poll round took the fabric from the two that matter
                 // (10 us per stage instead of 5)
                 if (tid == 0) {
                     T probe;
-                    while (!tv_load(rx, (unsigned)((d * NB + NB - 1) * TC_NR + TC_NR - 1) * 16u, tag, probe)) {
+                    while (!tv_load(rx, (unsigned)((d * NB + NB - 1) * NRC + NRC - 1) * 16u, tag, probe)) {
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_s_sleep(32);
                         if (++spins > TV_SPIN_LIMIT / 8) break;   // (the sweep below times out properly)
                     }
                 }
                 spins = 0;
-                __syncthreads();
+                tc_barrier();
+                if (cached_fetch == 2) {   // timing experiment (wrong results): a bystander fetches one granule per thread instead of GP
+                    (void)tv_load(rx, goff, tag, v[0]);
+#pragma unroll
+                    for (int j = 1; j < GP; ++j) v[j] = v[0];
+                    miss = 0;
+                } else if (cached_fetch) {
+                    // x_d is (almost certainly) complete in memory: fetch it through the L2; what a cached read misses is fetched again below
+                    bool okj[GP];
+#pragma unroll
+                    for (int j = 0; j < GP; ++j) okj[j] = tv_load_cached(rx, goff + (unsigned)j * 16u, tag, v[j]);
+                    miss = 0;
+#pragma unroll
+                    for (int j = 0; j < GP; ++j) miss |= okj[j] ? 0u : (1u << j);
+                }
             }
             while (miss) {
                 asm volatile("" ::: "memory");
-                // all sixteen requests in flight before the first tag is looked at (a test between two loads makes them sixteen
-                // dependent round trips: 12 us per stage instead of 5)
-                bool okj[16];
+                // all requests in flight before the first tag is looked at (a test between two loads makes them dependent round trips:
+                // 12 us per stage instead of 5)
+                bool okj[GP];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) okj[j] = tv_load(rx, goff + (unsigned)j * 16u, tag, v[j]);
+                for (int j = 0; j < GP; ++j) okj[j] = tv_load(rx, goff + (unsigned)j * 16u, tag, v[j]);
                 miss = 0;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) miss |= okj[j] ? 0u : (1u << j);
+                for (int j = 0; j < GP; ++j) miss |= okj[j] ? 0u : (1u << j);
                 if (miss) {
                     if (!urgent) __builtin_amdgcn_s_sleep(8);
                     if (++spins > TV_SPIN_LIMIT) { timed_out = true; break; }
                 }
             }
-            volatile T* vx = xd;
+            TC_STAMP_WG(s, 1);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) vx[k * TC_XLD + cb + j] = v[j];
+            for (int j = 0; j < GP; ++j) {
+                xd[k * TC_XLD + cb + j] = v[j];
+                asm volatile("" ::: "memory");   // (see stage_c)
+            }
             if (timed_out) {
                 s_dead = 1;
                 __hip_atomic_store((unsigned long long*)(err + 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        __syncthreads();
+        tc_barrier();
         if (s_dead) return;
+        TC_STAMP_WG(s, 2);
+        if (ns == dnext) TC_STAMP_OWN(ns, 1);
+        if constexpr (PREFETCH) {
+            pre_valid = s + 2 < nb && w != owner_of(dnext) && owned_from(dnext + dir) >= 0;
+            if (pre_valid) {
+                const unsigned goff = (unsigned)((dnext * NB + (tid >> 2)) * NRC + (tid & 3) * GP) * 16u;
+#pragma unroll
+                for (int j = 0; j < GP; ++j) praw[j] = tv_load_raw(rx, goff + (unsigned)j * 16u);
+            }
+        }
         // ---- the chain: the next block is this workgroup's.  x_next = y + (-M) x_d: the accumulators start from y
         if (ns == dnext) {
-            acc_t mx[4];
+            acc_t mx[FR];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) mx[t] = yv[t];
-            tc_mma<T>(mcrit, xd, lane, mx);
+            for (int t = 0; t < FR; ++t) mx[t] = yv[t];
+            tc_mma<T, FR, TC_XLD>(mcrit, xd, lane, mx);
+            TC_STAMP_OWN(ns, 2);
             publish(ns, mx, xs[(s + 1) & 1]);
-            ns = owned_from(ns + dir * G);
-            load_crit();
-            if (single) break;   // (its only block is solved)
+            TC_STAMP_PUB(ns);
+            advance();
         }
-        // ---- T_rd x_d off the blocks owned further on, the nearest first (its -T came a stage ago)
-        bool first = true;
-        for (int r = owned_from(dnext + dir); r >= 0; r = owned_from(r + dir * G)) {
-            if (!first) tc_load_a<T>(R + (int64_t)r * NB * ld + d * NB, ld, rows_of(r), min(NB, n - d * NB), wave, lane, tnear, true);
-            first = false;
-            if (single) {
-                tc_mma<T>(tnear, xd, lane, cacc);
-            } else {
-                load_c(r, cacc);
-                tc_mma<T>(tnear, xd, lane, cacc);
-                store_c(r, cacc);
-            }
-            if (r == dnext + dir && r == ns) {
-                // the block after next is this workgroup's: everything but x_next has reached it -- its y (the tile is in registers)
-                stage_c(ys, cacc);
-                __syncthreads();
+        TC_STAMP_WG(s, 3);
+        // ---- T_rd x_d off the blocks owned further on.  The current run (registers) in straight-line code: a loop here makes hipcc wait
+        // for EVERY outstanding memory access at its header and at its exit (loads issued ahead, store acknowledgements: ~2 us each)
+        int last_q = qof(dnext);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) yv[t] = acc_t{T(0), T(0), T(0), T(0)};
-                tc_mma<T>(dcrit, ys, lane, yv);
+        for (int kk = 0; kk < RUN; ++kk) {
+            const int r = cur_first < 0 ? -1 : cur_first + dir * kk;
+            const bool mine = r >= 0 && r < nb && qof(r) / RUN == qof(cur_first) / RUN && qof(r) > qof(dnext);   // (workgroup-uniform)
+            if (mine) {
+                last_q = qof(r);
+                if (!(tn_blk[kk] == r && tn_col == d))   // (a run that has just become current: its -T was not asked for)
+                    tc_load_a<T>(R + (int64_t)r * NB * ld + d * NB, ld, rows_of(r), min(NB, n - d * NB), wave, lane, tnear[kk], true);
+                tc_mma<T, FR, TC_XLD>(tnear[kk], xd, lane, racc[kk]);
+                // the block after next is this workgroup's next: everything but x_next has reached it -- its y
+                if (r == dnext + dir && r == ns) make_y(racc[kk], dcrit, yv);
             }
         }
-        if (s + 2 < nb) {   // -T of the next stage's nearest trailing block
-            const int rn = owned_from(dnext + 2 * dir);
-            if (rn >= 0) tc_load_a<T>(R + (int64_t)rn * NB * ld + dnext * NB, ld, rows_of(rn), min(NB, n - dnext * NB), wave, lane, tnear, true);
+        TC_STAMP_WG(s, 4);
+        // the next stage's -T for the run in registers: on its way while this stage ends and the next x arrives
+        if (s + 2 < nb) request_t(dnext, qof(dnext) + 1);
+        // runs further on live in X (matrices of more than RUN * G blocks only)
+        if (last_q + 1 < nb && owned_from(rof(last_q + 1)) >= 0) {
+            for (int r = owned_from(rof(last_q + 1)); r >= 0; r = owned_from(r + dir)) {
+                if (run_index(r) >= 0) continue;
+                T tf[16];
+                tc_load_a<T>(R + (int64_t)r * NB * ld + d * NB, ld, rows_of(r), min(NB, n - d * NB), wave, lane, tf, true);
+                acc_t c[FR];
+                load_c(r, c);
+                tc_mma<T, FR, TC_XLD>(tf, xd, lane, c);
+                store_c(r, c);
+            }
         }
-        __syncthreads();  // everybody is done with xs[s & 1] / ys before the stage after next rewrites them
+        tc_barrier();  // everybody is done with xs[s & 1] / ys before the stage after next rewrites them
+        TC_STAMP_WG(s, 5);
     }
 }
 
@@ -685,11 +857,24 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
                 a = b = 0;
             }
             int c = 0, d = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&trsm_chain_kernel<T, false>), TV_THREADS, 0) != hipSuccess ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, reinterpret_cast<const void*>(&trsm_chain_kernel<T, true>), TV_THREADS, 0) != hipSuccess) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&trsm_chain_kernel<T, false, TC_NR, 1>), TV_THREADS, 0) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, reinterpret_cast<const void*>(&trsm_chain_kernel<T, true, TC_NR, 1>), TV_THREADS, 0) != hipSuccess) {
                 (void)hipGetLastError();
                 c = d = 0;
             }
+            int e = 0, f = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, reinterpret_cast<const void*>(&trsm_chain_kernel<T, false, 16, 2>), TV_THREADS, 0) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, reinterpret_cast<const void*>(&trsm_chain_kernel<T, true, 16, 2>), TV_THREADS, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                e = f = 0;
+            }
+            h->trsm16_per_cu = std::min(e, f);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, reinterpret_cast<const void*>(&trsm_chain_kernel<T, false, 32, 1>), TV_THREADS, 0) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, reinterpret_cast<const void*>(&trsm_chain_kernel<T, true, 32, 1>), TV_THREADS, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                e = f = 0;
+            }
+            h->trsm32_per_cu = std::min(e, f);
             h->trsv_max_wgs = std::max(1, std::min(std::min(a, b), std::min(c, d)) * h->num_cus);
         }
         if ((int)grid > h->trsv_max_wgs) {
@@ -697,16 +882,75 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
             return RFLU_ERR_ARG;
         }
     }
+    static const int dbg_skip = getenv("RFLU_DBG_SOLVE_SKIP") ? atoi(getenv("RFLU_DBG_SOLVE_SKIP")) : 0;   // timing only: 1 = no chain kernels, 2 = L only, 3 = U only
+    if (wide && dbg_skip == 1) return RFLU_OK;
     if (wide) {
+        // a pass of up to 64 columns as ONE chain of 64, TWO of 32 or FOUR of 16 columns side by side (trsm_chain_kernel); the narrower
+        // chains need all their workgroups on the device together
+        const int mode = h->tune.trsm_chain_split;   // 0: 64 x 1, 1: 16 x 4 in runs of two blocks, 2: 32 x 2
         for (int64_t c0 = 0; c0 < nrhs; c0 += TC_NR) {
             const int nr = (int)std::min<int64_t>(TC_NR, nrhs - c0);
-            ProfScope ps(h, RFLU_K_TRSM, 2.0 * (double)n * (double)n * (double)nr, sizeof(T) * (double)n * (double)n);
-            hipLaunchKernelGGL((trsm_chain_kernel<T, false>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Linv, Lsub, B + c0, ldb,
-                               xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev);
-            hipLaunchKernelGGL((trsm_chain_kernel<T, true>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Uinv, Usub, B + c0, ldb,
-                               xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev);
+            const int nrc = mode == 1 ? 16 : mode == 2 ? 32 : TC_NR;
+            const int chains = (nr + nrc - 1) / nrc;
+            const int run = mode == 1 ? 2 : 1;
+            const int per_cu = mode == 1 ? h->trsm16_per_cu : mode == 2 ? h->trsm32_per_cu : 1;
+            const int64_t want = (nb + run - 1) / run;
+            const int g = (int)std::min<int64_t>(want, (int64_t)per_cu * h->num_cus / chains);
+            const bool split = mode != 0 && per_cu > 0 && (g >= 32 || g == want);
+            ProfScope ps(h, RFLU_K_TRSM, 2.0 * (double)n * (double)n * (double)nr, sizeof(T) * (double)n * (double)n * (split ? chains : 1));
+            const unsigned per_chain = (unsigned)((size_t)nb * NB * nrc * 16);
+            const dim3 gs((unsigned)(g * chains));
+            if (split && mode == 1) {
+                if (dbg_skip != 3) hipLaunchKernelGGL((trsm_chain_kernel<T, false, 16, 2>), gs, dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Linv, Lsub, B + c0, ldb,
+                                   xchg, per_chain, ++h->trsv_tag, h->info_dev, chains, h->tune.trsm_chain_cached);
+                if (dbg_skip != 2) hipLaunchKernelGGL((trsm_chain_kernel<T, true, 16, 2>), gs, dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Uinv, Usub, B + c0, ldb,
+                                   xchg, per_chain, ++h->trsv_tag, h->info_dev, chains, h->tune.trsm_chain_cached);
+            } else if (split && mode == 2) {
+                if (dbg_skip != 3) hipLaunchKernelGGL((trsm_chain_kernel<T, false, 32, 1>), gs, dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Linv, Lsub, B + c0, ldb,
+                                   xchg, per_chain, ++h->trsv_tag, h->info_dev, chains, h->tune.trsm_chain_cached);
+                if (dbg_skip != 2) hipLaunchKernelGGL((trsm_chain_kernel<T, true, 32, 1>), gs, dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Uinv, Usub, B + c0, ldb,
+                                   xchg, per_chain, ++h->trsv_tag, h->info_dev, chains, h->tune.trsm_chain_cached);
+            } else {
+                if (dbg_skip != 3) hipLaunchKernelGGL((trsm_chain_kernel<T, false, TC_NR, 1>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Linv, Lsub, B + c0, ldb,
+                                   xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev, 1, h->tune.trsm_chain_cached);
+                if (dbg_skip != 2) hipLaunchKernelGGL((trsm_chain_kernel<T, true, TC_NR, 1>), dim3(grid), dim3(TV_THREADS), 0, h->stream, (int)n, nr, R, ld, Uinv, Usub, B + c0, ldb,
+                                   xchg, (unsigned)xchg_bytes, ++h->trsv_tag, h->info_dev, 1, h->tune.trsm_chain_cached);
+            }
             RFLU_HIP(hipGetLastError());
         }
+#ifdef RFLU_TC_TRACE
+        if (sizeof(T) == 8) {
+            static long long pub[2][1024], wg[2][1024][6], own[2][1024][4];
+            RFLU_HIP(hipMemcpyFromSymbol(own, HIP_SYMBOL(tc_trace_own), sizeof(own)));
+            RFLU_HIP(hipStreamSynchronize(h->stream));
+            RFLU_HIP(hipMemcpyFromSymbol(pub, HIP_SYMBOL(tc_trace_pub), sizeof(pub)));
+            RFLU_HIP(hipMemcpyFromSymbol(wg, HIP_SYMBOL(tc_trace_wg), sizeof(wg)));
+            for (int tri = 0; tri < 2; ++tri) {
+                fprintf(stderr, "[tc trace] triangle %d: publish-to-publish (us) for blocks in solve order 100..116:", tri);
+                for (int q = 100; q < 116 && q + 1 < (int)nb; ++q) {
+                    const int r0 = tri ? (int)nb - 1 - q : q, r1 = tri ? r0 - 1 : r0 + 1;
+                    fprintf(stderr, " %.2f", (pub[tri][r1] - pub[tri][r0]) / 100.0);
+                }
+                fprintf(stderr, "\n   per block q: previous publish -> top of its stage / x landed / product done / published:");
+                for (int q = 100; q < 108 && q + 1 < (int)nb; ++q) {
+                    const int r = tri ? (int)nb - 1 - q : q, rp = tri ? r + 1 : r - 1;
+                    fprintf(stderr, "  [%d] %.2f %.2f %.2f %.2f", q, (own[tri][r][0] - pub[tri][rp]) / 100.0, (own[tri][r][1] - pub[tri][rp]) / 100.0, (own[tri][r][2] - pub[tri][rp]) / 100.0, (pub[tri][r] - pub[tri][rp]) / 100.0);
+                }
+                const int qa = 40, qb = (int)std::min<int64_t>(nb, 1024) - 40;
+                const int ra = tri ? (int)nb - 1 - qa : qa, rb = tri ? (int)nb - 1 - qb : qb;
+                fprintf(stderr, "\n   average %.2f us per block over %d..%d\n", (pub[tri][rb] - pub[tri][ra]) / 100.0 / (qb - qa), qa, qb);
+                double acc[5] = {0, 0, 0, 0, 0}, top = 0; int cnt = 0;
+                for (int s = 40; s < qb; ++s) {
+                    if (!wg[tri][s][0] || !wg[tri][s][5] || !wg[tri][s][1]) continue;
+                    for (int i = 0; i < 5; ++i) acc[i] += (wg[tri][s][i + 1] - wg[tri][s][i]) / 100.0;
+                    if (wg[tri][s + 1][0]) top += (wg[tri][s + 1][0] - wg[tri][s][5]) / 100.0;
+                    ++cnt;
+                }
+                if (cnt) fprintf(stderr, "   bystander workgroup, %d stages: wait+fetch %.2f, LDS+barrier %.2f, prefetch issue+chain %.2f, owned loop %.2f, -T request+barrier %.2f, to next stage %.2f us\n",
+                                 cnt, acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, top / cnt);
+            }
+        }
+#endif
         return RFLU_OK;
     }
     for (int64_t c0 = 0; c0 < nrhs; c0 += TV_NR) {

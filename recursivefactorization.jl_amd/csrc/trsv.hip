@@ -395,7 +395,7 @@ constexpr int TC_NR = 64;                 // right-hand sides per pass
 // (blockIdx / G = chain): a stage then moves 16 KB of granules and one MFMA fragment per wave instead of 64 KB and four, and the factor
 // is read once per chain (4 GiB instead of 1 per triangle at n = 16384: still under the stage time).  n = 16384, 64 right-hand sides:
 // 5.9 -> see DESIGN.md section 7.
-constexpr int tc_xld(int nrc) { return nrc % 32 == 16 ? nrc : (nrc + 16) % 32 == 16 ? nrc + 16 : nrc + 32; }   // LDS row pitch of x_d ([k][column]; == 16 mod 32 doubles: conflict-free fragment reads)
+constexpr int tc_xld(int nrc) { return nrc + 1; }   // LDS row pitch of x_d ([k][column]): odd -- the four k groups of a fragment read (rows 16 apart) land 16 doubles apart in the banks
 
 template <typename T>
 struct TcMfma;
@@ -413,16 +413,29 @@ struct TcMfma<float> {
 };
 
 // A fragments of a 64 x 64 block M (row-major, leading dimension ldm; rows >= rows_ok / columns >= cols_ok read as zero):
-// lane (fi = lane & 15, fk = lane >> 4) of wave w holds M[16w + fi][4 kk + fk], kk = 0..15
+// lane (fi = lane & 15, fk = lane >> 4) of wave w holds M[16w + fi][16 fk + kk], kk = 0..15 -- 128 contiguous bytes of its row (Float64),
+// so a whole block arrives as eight 16-byte loads per lane.  (Which k a (lane, kk) slot of the MFMA stands for is free as long as
+// the B operand agrees: tc_mma reads x row 16 fk + kk for it.)
 template <typename T>
 __device__ __forceinline__ void tc_load_a(const T* __restrict__ M, int64_t ldm, int rows_ok, int cols_ok, int wave, int lane, T (&a)[16], bool neg)
 {
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
     const int fi = lane & 15, fk = lane >> 4;
     const int row = wave * 16 + fi;
-    const T* Mp = M + (int64_t)row * ldm + fk;
+    const T* Mp = M + (int64_t)row * ldm + 16 * fk;
+    if (rows_ok >= NB && cols_ok >= NB && ((reinterpret_cast<uintptr_t>(M) | (uintptr_t)(ldm * (int64_t)sizeof(T))) & 15) == 0) {   // (wave-uniform)
+#pragma unroll
+        for (int v = 0; v < 16 / VW; ++v) {
+            const vec_t x = *reinterpret_cast<const vec_t*>(Mp + v * VW);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) a[v * VW + e] = neg ? -x[e] : x[e];
+        }
+        return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-        const T v = (row < rows_ok && 4 * kk + fk < cols_ok) ? Mp[4 * kk] : T(0);
+        const T v = (row < rows_ok && 16 * fk + kk < cols_ok) ? Mp[kk] : T(0);
         a[kk] = neg ? -v : v;
     }
 }
@@ -434,7 +447,7 @@ __device__ __forceinline__ void tc_mma(const T (&a)[16], const T* xs, int lane, 
     const int fi = lane & 15, fk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-        const T* xr = xs + (4 * kk + fk) * XLD + fi;
+        const T* xr = xs + (16 * fk + kk) * XLD + fi;
 #pragma unroll
         for (int t = 0; t < FR; ++t) acc[t] = TcMfma<T>::run(a[kk], xr[16 * t], acc[t]);
     }

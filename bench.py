@@ -545,6 +545,7 @@ def main():
         regenerate(); step(); barrier()
         solve_cm_ms = time_solve(f"rflu_getrs_{sfx}_dev")          # column-major factors: + one transpose of F into the row-major workspace
         solve_ms = None
+        solve64_ms = None
         if n % 16 == 0:
             regenerate(); barrier()
             h.call(f"rflu_getrf_rm_{sfx}_dev", n, n, ctypes.c_void_p(A.data_ptr()), n, ctypes.c_void_p(ipiv.data_ptr()), 1, 0, ctypes.byref(info))
@@ -552,12 +553,30 @@ def main():
             bsol16[:, 0] = bkeep
             bkeep, bsol = bsol16.clone(), bsol16
             solve_ms = time_solve(f"rflu_getrs_rm_{sfx}_dev")      # the factors as the library keeps them: the solve kernels alone
+            # a BLOCK of 64 right-hand sides on the same factors (trsv.hip: trsm_chain_kernel, two chains of 32 columns on the MFMA units)
+            b64 = torch.rand((n, 64), dtype=tdt, device=dev)
+            b64k = b64.clone()
+            def solve64_once():
+                h.call(f"rflu_getrs_rm_{sfx}_dev", n, 64, ctypes.c_void_p(A.data_ptr()), n, ctypes.c_void_p(ipd.data_ptr() if ipd is not None else 0),
+                       ctypes.c_void_p(b64.data_ptr()), 64)
+            solve64_once(); barrier()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(5):
+                b64.copy_(b64k)
+                solve64_once()
+            s1.record()
+            barrier()
+            solve64_ms = s0.elapsed_time(s1) / 5
+            del b64, b64k
         variants = {
             "solve_ms": round(solve_ms, 3) if solve_ms is not None else None,
             "solve_cm_ms": round(solve_cm_ms, 3),
+            "solve64_ms": round(solve64_ms, 3) if solve64_ms is not None else None,
             "solve_note": "ldiv!(F, b), one right-hand side, pivoted factors: interchanges of b + L and U solves (csrc/trsv.hip: one "
                           "cooperative launch per triangle).  solve_ms: rflu_getrs_rm_*_dev on row-major factors (the solve kernels alone; "
-                          "algorithmic bytes sizeof(T) * n^2); solve_cm_ms: rflu_getrs_*_dev on column-major factors (+ one transpose of F)",
+                          "algorithmic bytes sizeof(T) * n^2); solve_cm_ms: rflu_getrs_*_dev on column-major factors (+ one transpose of F); "
+                          "solve64_ms: rflu_getrs_rm_*_dev with a row-major n x 64 block of right-hand sides",
             "solve_gbs": round(esz * n * n / (solve_ms * 1e-3) / 1e9, 1) if solve_ms else None,
             "nopivot": {"ms": round(1e3 * t_np, 3), "gflops": round(flops / t_np / 1e9, 1),
                         "frac_of_mfma_peak": round(flops / t_np / 1e12 / PEAK_TFLOPS[sfx], 4),
@@ -596,7 +615,9 @@ def main():
             host_entry = {"host_to_host_ms": round(1e3 * hh, 2), "factor_ms": round(ms_per_step, 3),
                           "pcie_bytes_each_way": esz * n * n,
                           "note": "rflu_getrf_* on a pageable host array (lu! of a host matrix): copy in, factor, factors and ipiv back in "
-                                  "the caller's array; best of two warm calls, wall clock around the call"}
+                                  "the caller's array; best of two warm calls, wall clock around the call.  Float64 pivoted square / tall "
+                                  "8192..16384: the matrix arrives block column by block column WHILE it is factored (driver.cpp: "
+                                  "getrf_host_engine, the persistent update engine of csrc/engine.hip), rows leave as they become final"}
             del keep, Ah
 
     # ---- checks on the last factorization: residual on device (torch as an independent checker) ----

@@ -59,7 +59,8 @@ out = [f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}): python benc
 out += [r[3] for r in rows]
 out += ["", "# default bench line of the same call (python bench.py --steps 8 --warmup 2), extra keys:"]
 rf = dflt["roofline"]
-out.append("# roofline: " + json.dumps({k: rf.get(k) for k in ("achieved", "frac", "achieved_in_schedule", "frac_in_schedule", "avg_launch_ms", "traffic")}))
+out.append("# roofline: " + json.dumps({k: rf.get(k) for k in ("achieved", "frac", "achieved_profiled", "frac_profiled", "achieved_in_schedule", "frac_in_schedule", "avg_launch_ms", "traffic") if k in rf}))
+out.append("# host_entry: " + json.dumps(dflt.get("host_entry")))
 lw = dflt.get("laswp") or {}
 out.append(f"# laswp.wide: {json.dumps(lw.get('wide'))}  all launches: {lw.get('achieved')} GB/s, {lw.get('total_ms')} ms")
 out.append(f"# laswp.alone: {json.dumps(lw.get('alone'))}")
@@ -81,5 +82,8 @@ block("# row interchanges alone (scripts/microbench_laswp.py: 512 interchanges x
 block("# host-pointer entry (scripts/microbench_host_entry.py, one caller buffer refilled in place):", "host_entry.txt")
 block("# cooperative leaf alone on the GPU (scripts/panel_bench.py, mode 2 = shipped kernel):", "panel_bench.txt", keep="mode 2")
 block("# solve step ldiv!(F, B) on row-major device factors (scripts/microbench_getrs.py):", "getrs.txt")
+block("# blocks of right-hand sides: the cooperative MFMA chain against the recursive splitting (scripts/getrs_check.py):", "getrs_block.txt")
+block("# the persistent update engine against the stream schedule (scripts/engine_check.py time; best of 4, ms):", "engine_time.txt")
+block("# cooperative leaf alone: any placement (mode 2, shipped routing above 4096 rows) against XCD-local (mode 1) (scripts/panel_bench.py):", "panel_bench_local.txt")
 open(os.path.join(P, f"{tag}_sizes.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out[:16]))

@@ -278,7 +278,11 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
     if constexpr (C >= 0) RFLU_STAMP(p.scratch, C, 0, g, tid);
     if constexpr (C >= 0) {
         // the whole hand-over in one LDS round trip, requested before anything is tested
-        const volatile XHand<T>* hv = &sh->hand[C & 1];
+        // (a plain read: barrier A in front of it is an asm statement that clobbers memory, so nothing is carried over from an earlier
+        // step.  Round 4 read it through a `volatile` pointer -- hipcc turned that into SIX flat loads (sc0 sc1) with an
+        // s_waitcnt vmcnt(0) behind each: six dependent trips through the vector memory path to LDS, each also waiting for the
+        // acknowledgement of the row-record stores in flight, at the top of every pivot step of every row wave)
+        const XHand<T>* hv = &sh->hand[C & 1];
         const T h_scale = hv->scale, h_wu = hv->wu, h_p1 = hv->p1, h_p2 = hv->p2;
         const unsigned h_win = hv->win, h_cpos = hv->cpos;
         if (h_win == POS_DEAD) { st.dead = true; return; }

@@ -65,31 +65,91 @@ __device__ __forceinline__ void eng_release()
 // row of any height: the solved blocks X_e are read back from memory (this workgroup's own stores, drained + barrier) instead of
 // being kept in LDS, so W = 512 ... 2048 rows cost 24 KB of LDS; a leaf (64 rows) is the loop's first round alone.  Wave w owns
 // rows [16w, 16w+16) of a 64-row block x 32 columns.
+// The unit functions are real calls (inlined, the three of them spill), and across a call boundary -- or through an argument struct
+// whose address has been taken, which then lives in scratch memory -- hipcc no longer knows which address space a pointer belongs to:
+// every global access of the first build was a FLAT instruction, 460 in the tile function alone.  Flat loads count on vmcnt AND
+// lgkmcnt, so every wait for an LDS read of the GEMM's inner loop was also a wait for the operand slab requested ahead.  The units
+// therefore get their pointers by VALUE with the address space in the type (a cast global -> generic at the top of the function is what
+// the address-space inference reads; generic -> global -> generic is folded away, an __builtin_assume is ignored).
 template <typename T>
-__device__ __attribute__((noinline)) void eng_prep_unit(const EngArgs<T>& a, const EngOp o, int u, T* smem)
+struct EngUnit {
+    typedef T __attribute__((address_space(1))) GT;
+    typedef int __attribute__((address_space(1))) GI;
+    typedef T __attribute__((address_space(3))) LT;
+    GT* R;
+    const GT* linv;
+    const GI* pm_cnt;
+    const GI* pm_dst;
+    const GI* pm_src;
+    LT* smem;
+    int64_t ld;
+    EngGeo g;
+    int gemm_flags;
+    int x2;
+};
+template <typename P>
+__device__ __forceinline__ P* eng_launder(P* p)   // experiment builds: hide where a pointer comes from (its accesses become flat again)
 {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+v"(v));
+    return (P*)v;
+}
+#ifdef ENG_FLAT_PREP
+#define ENG_PREP_PTR(p) eng_launder(p)
+#else
+#define ENG_PREP_PTR(p) (p)
+#endif
+#ifdef ENG_FLAT_GEMM
+#define ENG_GEMM_PTR(p) eng_launder(p)
+#else
+#define ENG_GEMM_PTR(p) (p)
+#endif
+template <typename T>
+__device__ __forceinline__ EngUnit<T> eng_unit_args(const EngArgs<T>& a, T* smem)
+{
+    EngUnit<T> u;
+    u.R = (typename EngUnit<T>::GT*)a.R;
+    u.linv = (const typename EngUnit<T>::GT*)a.linv;
+    u.pm_cnt = (const typename EngUnit<T>::GI*)a.pm_cnt;
+    u.pm_dst = (const typename EngUnit<T>::GI*)a.pm_dst;
+    u.pm_src = (const typename EngUnit<T>::GI*)a.pm_src;
+    u.smem = (typename EngUnit<T>::LT*)smem;
+    u.ld = a.ld;
+    u.g = a.g;
+    u.gemm_flags = a.gemm_flags;
+    u.x2 = a.x[2];
+    return u;
+}
+
+template <typename T>
+__device__ __attribute__((noinline)) void eng_prep_unit(const EngUnit<T> a, const EngOp o, int u)
+{
+    T* const smem = (T*)a.smem;
     typedef typename Mfma<T>::acc_t acc_t;
     constexpr int VW = 16 / (int)sizeof(T);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = o.j0, jb = o.jb;
     const int c0 = o.c_lo + u * EP_COLS;
     const int nc = min(EP_COLS, o.nc - u * EP_COLS);
-    T* const R = a.R;
+    T* const R = ENG_PREP_PTR((T*)a.R);
     const int64_t ld = a.ld;
+    const int* const pm_cnt = (const int*)a.pm_cnt;
+    const int* const pm_dst = (const int*)a.pm_dst;
+    const int* const pm_src = (const int*)a.pm_src;
     if (a.g.pivot) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         if (nc % VW == 0) {
             constexpr int SC = 8 * VW;
             if (wv < (nc + SC - 1) / SC)
-                laswp_strip<T, VW, 8>(R, ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, o.chunk0, o.chunk1, wv);
+                laswp_strip<T, VW, 8>(R, ld, c0, nc, 0, 0, 0, 0, pm_cnt, pm_dst, pm_src, o.chunk0, o.chunk1, wv);
         } else {
             if (wv < (nc + 7) / 8)
-                laswp_strip<T, 1, 8>(R, ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, o.chunk0, o.chunk1, wv);
+                laswp_strip<T, 1, 8>(R, ld, c0, nc, 0, 0, 0, 0, pm_cnt, pm_dst, pm_src, o.chunk0, o.chunk1, wv);
         }
         __syncthreads();   // (every chunk of laswp_strip ends with s_waitcnt vmcnt(0): the rows are in place)
     }
     const T* L = R + (int64_t)j0 * ld + j0;
-    const T* Linv = a.linv + (int64_t)(j0 / NB) * NB * NB;
+    const T* Linv = ENG_PREP_PTR((const T*)a.linv) + (int64_t)(j0 / NB) * NB * NB;
     T* B = R + (int64_t)j0 * ld + c0;
     const int nblk = (jb + NB - 1) / NB;
     const int fi = lane & 15, fk = lane >> 4;
@@ -158,22 +218,24 @@ __device__ __attribute__((noinline)) void eng_prep_unit(const EngArgs<T>& a, con
 
 // ---- stage 1: one 128 x 128 tile of A22 -= A21 * X --------------------------------------------------------------------------------
 template <typename T>
-__device__ __attribute__((noinline)) void eng_gemm_unit(const EngArgs<T>& a, const EngOp o, int t, T* smem)
+__device__ __attribute__((noinline)) void eng_gemm_unit(const EngUnit<T> a, const EngOp o, int t)
 {
     constexpr int VW = 16 / (int)sizeof(T);
+    T* const smem = (T*)a.smem;
+    T* const Rg = ENG_GEMM_PTR((T*)a.R);
     const int je = o.j0 + o.jb;
     GemmArgs<T> g;
     g.M = a.g.m - je;
     g.N = o.nc;
     g.K = o.jb;
-    g.A = a.R + (int64_t)je * a.ld + o.j0;
-    g.B = a.R + (int64_t)o.j0 * a.ld + o.c_lo;
-    g.C = a.R + (int64_t)je * a.ld + o.c_lo;
+    g.A = Rg + (int64_t)je * a.ld + o.j0;
+    g.B = Rg + (int64_t)o.j0 * a.ld + o.c_lo;
+    g.C = Rg + (int64_t)je * a.ld + o.c_lo;
     g.lda = g.ldb = g.ldc = a.ld;
     g.tiles_m = (g.M + G_BM - 1) / G_BM;
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
-    g.vec_ok = (reinterpret_cast<uintptr_t>(a.R) % 16 == 0) && (a.ld % VW == 0) && (o.c_lo % VW == 0) && (o.j0 % VW == 0);
-    g.flags = a.gemm_flags | ((a.x[2] & 1) ? 4 : 0);   // x[2] = 1: write-through C stores, no release fence behind a tile
+    g.vec_ok = (reinterpret_cast<uintptr_t>(Rg) % 16 == 0) && (a.ld % VW == 0) && (o.c_lo % VW == 0) && (o.j0 % VW == 0);
+    g.flags = a.gemm_flags | ((a.x2 & 1) ? 4 : 0);   // x[2] = 1: write-through C stores, no release fence behind a tile
     g.na_tiles_n = 0; g.sig_flag = nullptr; g.sig_val = 0; g.sig_cnt = nullptr;
     // G_GROUP_M tile rows are walked together, column after column: consecutive claims share the B panel, then the A panels
     int tile_m, tile_n;
@@ -201,7 +263,7 @@ __device__ __attribute__((noinline)) void eng_gemm_unit(const EngArgs<T>& a, con
 // still owe the interchanges of the leaves behind it in the same block column; left op lk >= 1: block column cb + lk as a whole, four
 // wave strips (of one 128-byte line per row) per unit
 template <typename T>
-__device__ __attribute__((noinline)) void eng_left_unit(const EngArgs<T>& a, int cb, int lk, int u)
+__device__ __attribute__((noinline)) void eng_left_unit(const EngUnit<T> a, int cb, int lk, int u)
 {
     constexpr int VW = 16 / (int)sizeof(T);
     constexpr int SC = 8 * VW;
@@ -223,12 +285,16 @@ __device__ __attribute__((noinline)) void eng_left_unit(const EngArgs<T>& a, int
         chunk1 = chunk0 + eng_leaves_of_block(a.g, pb + lk);
     }
     if (nc <= 0 || chunk1 <= chunk0) return;
+    T* const R = (T*)a.R;
+    const int* const pm_cnt = (const int*)a.pm_cnt;
+    const int* const pm_dst = (const int*)a.pm_dst;
+    const int* const pm_src = (const int*)a.pm_src;
     if (nc % VW == 0) {
         for (int s = wave; s < (nc + SC - 1) / SC; s += 4)
-            laswp_strip<T, VW, 8>(a.R, a.ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, s);
+            laswp_strip<T, VW, 8>(R, a.ld, c0, nc, 0, 0, 0, 0, pm_cnt, pm_dst, pm_src, chunk0, chunk1, s);
     } else {
         for (int s = wave; s < (nc + 7) / 8; s += 4)
-            laswp_strip<T, 1, 8>(a.R, a.ld, c0, nc, 0, 0, 0, 0, a.pm_cnt, a.pm_dst, a.pm_src, chunk0, chunk1, s);
+            laswp_strip<T, 1, 8>(R, a.ld, c0, nc, 0, 0, 0, 0, pm_cnt, pm_dst, pm_src, chunk0, chunk1, s);
     }
 }
 
@@ -239,6 +305,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char eng_smem_raw[];
     T* smem = reinterpret_cast<T*>(eng_smem_raw);
+    const EngUnit<T> ua = eng_unit_args<T>(a, smem);
     __shared__ int s_sel[4];   // kind, column block, sequence, unit
     EngState* const st = a.st;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -298,13 +365,16 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 }
             }
             for (int attempt = 0; kind == ENG_NONE; ++attempt) {
-                if (eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0) { kind = ENG_EXIT; break; }
                 // what this sweep is based on: if it finds nothing, the wave sleeps on these three words until one of them moves
                 const unsigned long long seen_epoch = eng_load(&st->epoch), seen_gate = eng_load(a.leaf_gate);
                 const unsigned long long seen_arr = a.arrived ? eng_load(a.arrived) : 0ull;
-                // (the three words must have been SAMPLED before the sweep's loads are issued: loads to different channels are served
-                // in any order, and a sweep older than the epoch it is paired with sleeps through the publication it missed)
+                // (the three words must have been SAMPLED before anything the sweep looks at is requested: loads to different channels
+                // are served in any order, and a sweep older than the epoch it is paired with sleeps through the publication it missed.
+                // That includes the count of unfinished column blocks: read in front of the epoch, the last publication of a
+                // factorization could fall between the two reads -- the workgroup then slept on the final epoch of a finished
+                // factorization and raised the timeout flag 4 s later: one call in ~200 at N=8192, scripts/engine_stress.py)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0) { kind = ENG_EXIT; break; }
                 const int pd = seen_gate > a.gate_base ? (int)(seen_gate - a.gate_base) : 0;
                 const int have = a.arrived ? (int)seen_arr : a.g.n;   // columns in place (host entry: they arrive while we run)
                 // ---- main units: one lane per column block -----------------------------------------------------------------
@@ -426,7 +496,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     int naps = 0;
                     for (;;) {
                         if (eng_load(&st->epoch) != seen_epoch || eng_load(a.leaf_gate) != seen_gate ||
-                            (a.arrived && eng_load(a.arrived) != seen_arr) || eng_load(&st->abort) != 0)
+                            (a.arrived && eng_load(a.arrived) != seen_arr) || eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0)
                             break;
                         naps = min(naps + 1, leaf_only ? 2 : 16);
                         for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(32);
@@ -455,10 +525,10 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
             const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
             if (a.trace && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == (o.j0 + o.jb + NB) / a.g.Wc)
                 a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 2 : 0)] = wall_clock64();
-            if ((seq & 1u) == 0) eng_prep_unit<T>(a, o, unit, smem);
-            else eng_gemm_unit<T>(a, o, unit, smem);
+            if ((seq & 1u) == 0) eng_prep_unit<T>(ua, o, unit);
+            else eng_gemm_unit<T>(ua, o, unit);
         } else {
-            eng_left_unit<T>(a, cb, (int)seq, unit);
+            eng_left_unit<T>(ua, cb, (int)seq, unit);
         }
         // ---- completion: drain every wave's stores, one lane releases and counts ------------------------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -87,23 +87,6 @@ struct EngUnit {
     int gemm_flags;
     int x2;
 };
-template <typename P>
-__device__ __forceinline__ P* eng_launder(P* p)   // experiment builds: hide where a pointer comes from (its accesses become flat again)
-{
-    unsigned long long v = (unsigned long long)p;
-    asm volatile("" : "+v"(v));
-    return (P*)v;
-}
-#ifdef ENG_FLAT_PREP
-#define ENG_PREP_PTR(p) eng_launder(p)
-#else
-#define ENG_PREP_PTR(p) (p)
-#endif
-#ifdef ENG_FLAT_GEMM
-#define ENG_GEMM_PTR(p) eng_launder(p)
-#else
-#define ENG_GEMM_PTR(p) (p)
-#endif
 template <typename T>
 __device__ __forceinline__ EngUnit<T> eng_unit_args(const EngArgs<T>& a, T* smem)
 {
@@ -131,7 +114,7 @@ __device__ __attribute__((noinline)) void eng_prep_unit(const EngUnit<T> a, cons
     const int j0 = o.j0, jb = o.jb;
     const int c0 = o.c_lo + u * EP_COLS;
     const int nc = min(EP_COLS, o.nc - u * EP_COLS);
-    T* const R = ENG_PREP_PTR((T*)a.R);
+    T* const R = (T*)a.R;
     const int64_t ld = a.ld;
     const int* const pm_cnt = (const int*)a.pm_cnt;
     const int* const pm_dst = (const int*)a.pm_dst;
@@ -149,7 +132,7 @@ __device__ __attribute__((noinline)) void eng_prep_unit(const EngUnit<T> a, cons
         __syncthreads();   // (every chunk of laswp_strip ends with s_waitcnt vmcnt(0): the rows are in place)
     }
     const T* L = R + (int64_t)j0 * ld + j0;
-    const T* Linv = ENG_PREP_PTR((const T*)a.linv) + (int64_t)(j0 / NB) * NB * NB;
+    const T* Linv = (const T*)a.linv + (int64_t)(j0 / NB) * NB * NB;
     T* B = R + (int64_t)j0 * ld + c0;
     const int nblk = (jb + NB - 1) / NB;
     const int fi = lane & 15, fk = lane >> 4;
@@ -222,7 +205,7 @@ __device__ __attribute__((noinline)) void eng_gemm_unit(const EngUnit<T> a, cons
 {
     constexpr int VW = 16 / (int)sizeof(T);
     T* const smem = (T*)a.smem;
-    T* const Rg = ENG_GEMM_PTR((T*)a.R);
+    T* const Rg = (T*)a.R;
     const int je = o.j0 + o.jb;
     GemmArgs<T> g;
     g.M = a.g.m - je;

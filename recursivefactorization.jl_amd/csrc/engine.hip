@@ -413,6 +413,26 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
                         if ((int)u < eng_units_of(o, (int)(seq & 1u), a.g.m)) {
                             kind = ENG_MAIN; sel_cb = cb; sel_seq = seq; sel_unit = (int)u;
+                            // Which tile of a whole-block-column update: the one the ticket names, or (x[7]) the next one of this XCD's band
+                            // of tile rows -- whoever comes first takes tiles in order, so the workgroups of one XCD would otherwise work on
+                            // tiles spread over the whole column block and every L2 would stream every operand panel of it
+                            if (a.x[7] > 0 && (seq & 1u) != 0 && o.type == ENG_OP_BIG) {
+                                const int tiles_m = (a.g.m - (o.j0 + o.jb) + G_BM - 1) / G_BM, tiles_n = (o.nc + G_BN - 1) / G_BN;
+                                const int units = tiles_m * tiles_n, per_group = G_GROUP_M * tiles_n, ngroups = (tiles_m + G_GROUP_M - 1) / G_GROUP_M;
+                                unsigned xcc;
+                                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                                int picked = -1;
+                                for (int k = 0; k < 8 && picked < 0; ++k) {
+                                    const int r = (int)((xcc + (unsigned)k) & 7u);
+                                    const int s0 = (r * ngroups / 8) * per_group, s1 = min(((r + 1) * ngroups / 8) * per_group, units);
+                                    if (s1 <= s0) continue;
+                                    unsigned long long i = 0;
+                                    if (lane == 0) i = __hip_atomic_fetch_add(&st->cb[cb].xclaim[r], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    i = __shfl(i, 0);
+                                    if (s0 + (int)i < s1) picked = s0 + (int)i;
+                                }
+                                if (picked >= 0) sel_unit = picked;   // (every ticket finds a tile: as many tiles as tickets)
+                            }
                             // The scan saw an eligible sequence; the add may have landed in a LATER one (published in between).  A later
                             // stage 1 is ready by construction; a later stage 0 needs its leaves -- practically never the case (a whole
                             // sequence would have to complete between this wave's scan and its add), but then the claim is held until
@@ -539,6 +559,8 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                     eng_store(&c->done, 0ull);
+                    if (a.x[7] > 0 && (seq & 1u) != 0 && o.type == ENG_OP_BIG)
+                        for (int r = 0; r < 8; ++r) eng_store(&c->xclaim[r], 0ull);
                     const unsigned end = 2u * (unsigned)eng_nops(a.g, cb);
                     unsigned ns = seq + 1;
                     while (ns < end && eng_units(a, cb, ns) == 0) ++ns;   // (an operation with no columns left, a panel with no rows below it)

@@ -30,6 +30,8 @@ struct EngCB {
     unsigned long long leftdone; // (first column block of a block column) own << 32 | left, see "order between the interchanges ..." below
     unsigned long long lprog;    // left operations completed (lprog >= 1: the block column's own later interchanges have reached this column block)
     unsigned long long bigdone;  // (first column block of a block column) column blocks that have completed BIG(this block column)
+    unsigned long long xclaim[8]; // tiles of the current whole-block-column update handed out per band of tile rows: the workgroups of XCD x start with
+                                 // band x (engine.hip: a ticket from `claim` says THAT a tile is due, these say WHICH), zeroed by whoever publishes the next sequence
 };
 
 struct EngState {

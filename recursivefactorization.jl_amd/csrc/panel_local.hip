@@ -282,9 +282,26 @@ __device__ __forceinline__ void x_step(const PanelArgs<T>& p, XLds<T>* sh, T (&a
         // step.  Round 4 read it through a `volatile` pointer -- hipcc turned that into SIX flat loads (sc0 sc1) with an
         // s_waitcnt vmcnt(0) behind each: six dependent trips through the vector memory path to LDS, each also waiting for the
         // acknowledgement of the row-record stores in flight, at the top of every pivot step of every row wave)
-        const XHand<T>* hv = &sh->hand[C & 1];
+        // ... and as ONE round trip: all 16-byte pieces requested together and pinned in registers by an empty asm statement, or hipcc
+        // reads the winner first, branches, reads the next two pieces, branches, reads the third (three dependent LDS latencies)
+        typedef unsigned xh_u4 __attribute__((ext_vector_type(4)));
+        constexpr int XH_Q = (int)(sizeof(XHand<T>) / 16);
+        static_assert(sizeof(XHand<T>) % 16 == 0, "XHand is read in 16-byte pieces");
+        xh_u4 xq[XH_Q];
+        {
+            const xh_u4* hq = reinterpret_cast<const xh_u4*>(&sh->hand[C & 1]);
+#pragma unroll
+            for (int i = 0; i < XH_Q; ++i) xq[i] = hq[i];
+#pragma unroll
+            for (int i = 0; i < XH_Q; ++i) asm volatile("" : "+v"(xq[i]));
+        }
+        XHand<T> hcopy;
+        __builtin_memcpy(&hcopy, xq, sizeof(hcopy));
+        const XHand<T>* hv = &hcopy;
         const T h_scale = hv->scale, h_wu = hv->wu, h_p1 = hv->p1, h_p2 = hv->p2;
-        const unsigned h_win = hv->win, h_cpos = hv->cpos;
+        // (the asm statement hides that the pieces came from a wave-uniform address: the two control words go back to scalar registers,
+        // or every test below turns into exec-mask arithmetic)
+        const unsigned h_win = (unsigned)__builtin_amdgcn_readfirstlane((int)hv->win), h_cpos = (unsigned)__builtin_amdgcn_readfirstlane((int)hv->cpos);
         if (h_win == POS_DEAD) { st.dead = true; return; }
         owner = st.pos == h_cpos && st.pos != POS_NONE;
         if constexpr (C >= 1) {

@@ -112,6 +112,7 @@ void Tune::load_env()
     env_get("RFLU_ENGINE_ROWS", engine_rows);
     env_get("RFLU_ENGINE_HOST", engine_host);
     env_get("RFLU_ENGINE_WC", engine_wc);
+    env_get("RFLU_ENGINE_RETIRE", engine_retire);
     for (int i = 0; i < 8; ++i) {
         char name[32];
         snprintf(name, sizeof(name), "RFLU_ENGINE_X%d", i);
@@ -979,6 +980,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     EngGeo geo{};
     EngState* est = nullptr;
     hipStream_t E = nullptr;
+    int64_t eng_retire_leaf = -1;   // engine mode: the leaf in front of which the engine's workgroups on the chain's XCD are gone (-1: they stay)
     struct RestoreLocal { Handle* h; int64_t rows; bool on; ~RestoreLocal() { if (on) h->tune.panel_local_rows = rows; } } restore_local{h, h->tune.panel_local_rows, false};
     if (eng_end > 0) {
         if (b_begin != 0) { set_error("factor_leafwise: the engine starts at block column 0"); return RFLU_ERR_ARG; }
@@ -1025,6 +1027,19 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         a.arrived = h->eng_host_mode ? &est->arrived : nullptr;
         a.rows_final = h->eng_host_mode ? h->eng_rows_final_dev : nullptr;
         for (int i = 0; i < 8; ++i) a.x[i] = h->tune.engine_x[i];
+        // Engine to the end: from the first panel of at most `local_rows` rows on the chain wants its XCD-local leaves back (worth 1.2 ms at
+        // N=16384), and the engine has little left to do: its workgroups on the chain's XCD retire two leaves earlier, the first such
+        // leaf waits until they are gone (RFLU_ENGINE_RETIRE=0: they stay, every leaf any-placement)
+        eng_retire_leaf = -1;
+        a.retire_xcc = -1; a.retire_leaf = 0;
+        {
+            const int64_t local_rows = restore_local.rows >= 0 ? restore_local.rows : (sizeof(T) == 4 ? 8192 : 4096);
+            if (h->tune.engine_retire && eng_end >= nblk && !h->eng_host_mode && f.pivot && h->panel_local == 2 && !h->coop_launch && local_rows >= 1024 && m > local_rows + 4 * NB) {
+                eng_retire_leaf = (m - local_rows + NB - 1) / NB;   // first leaf whose panel has at most local_rows rows
+                a.retire_xcc = h->panel_xcc;
+                a.retire_leaf = (int)std::max<int64_t>(1, eng_retire_leaf - 2);
+            }
+        }
         a.trace = nullptr;
         static long long* eng_trace_buf = nullptr;   // measurement only (RFLU_ENGINE_TRACE=1): stamps of the leaf windows, printed at the next call
         if (env_str("RFLU_ENGINE_TRACE")) {
@@ -1088,6 +1103,10 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             RFLU_TRY(launch_eng_wait(h, &est->arrived, (unsigned long long)std::min<int64_t>(n, je + NB)));
         for (int64_t i = 0; i < nl; ++i) {
             const int64_t g = g0 + i, c0 = j0 + i * NB, w = std::min<int64_t>(NB, je - c0);
+            if (in_eng && g == eng_retire_leaf) {   // the chain's XCD is its own again: XCD-local leaves from here on
+                RFLU_TRY(launch_eng_wait_retired(h, h->panel_xcc));
+                h->tune.panel_local_rows = restore_local.rows;
+            }
             RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, f.ipiv, f.pivot));
             const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);
             const unsigned long long* wflag = nullptr;   // leaf g-1 reached LA through the side stream: in its own block's part, or the next block's

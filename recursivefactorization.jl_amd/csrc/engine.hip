@@ -295,6 +295,11 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
     int cb_lo = 0;             // column blocks in front of this one have nothing left for the main scan (monotone)
     int fin_b = 0;             // workgroup 0: block rows [0, fin_b) have been reported final (EngArgs::rows_final)
     // x[4] = m > 0: workgroups with blockIdx % m == 1;  x[5] = k > 0: the workgroups of k XCDs (blockIdx % 8 in [1, k]);  x[6] = j > 0: of those, only blockIdx / 8 < j
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 7u;
+    if (tid == 0) __hip_atomic_fetch_add(&st->xcc_wgs[my_xcc], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool may_retire = a.retire_leaf > 0 && (int)my_xcc == a.retire_xcc;
     bool leaf_only = a.x[4] > 0 && (int)(blockIdx.x % (unsigned)a.x[4]) == 1;
     if (a.x[5] > 0) leaf_only = (int)(blockIdx.x & 7) >= 1 && (int)(blockIdx.x & 7) <= a.x[5] && (a.x[6] <= 0 || (int)(blockIdx.x >> 3) < a.x[6]);
 
@@ -360,6 +365,12 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 if (eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0) { kind = ENG_EXIT; break; }
                 const int pd = seen_gate > a.gate_base ? (int)(seen_gate - a.gate_base) : 0;
                 const int have = a.arrived ? (int)seen_arr : a.g.n;   // columns in place (host entry: they arrive while we run)
+                // the chain has reached its short panels: the workgroups on ITS XCD go home (one count each, the critical path waits for the sum)
+                if (may_retire && pd >= a.retire_leaf) {
+                    if (lane == 0) __hip_atomic_fetch_add(&st->retired, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    kind = ENG_EXIT;
+                    break;
+                }
                 // ---- main units: one lane per column block -----------------------------------------------------------------
                 int best = INT_MAX;
                 int first_live = INT_MAX;
@@ -644,6 +655,28 @@ __global__ void eng_wait_kernel(const unsigned long long* flag, unsigned long lo
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ void eng_wait_retired_kernel(const unsigned long long* retired, const unsigned long long* target, unsigned long long* abort, int64_t* info)
+{
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > 400000000LL) {
+            __hip_atomic_fetch_or((unsigned long long*)(info + 1), 33ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+int launch_eng_wait_retired(Handle* h, int xcc)
+{
+    EngState* st = static_cast<EngState*>(h->eng_state);
+    hipLaunchKernelGGL(eng_wait_retired_kernel, dim3(1), dim3(1), 0, h->stream, &st->retired, &st->xcc_wgs[xcc & 7], &st->abort, h->info_dev);
+    RFLU_HIP(hipGetLastError());
+    return RFLU_OK;
 }
 
 int launch_eng_wait(Handle* h, const unsigned long long* flag, unsigned long long value)

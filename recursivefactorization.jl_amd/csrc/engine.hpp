@@ -40,7 +40,10 @@ struct EngState {
     unsigned long long abort;        // != 0: leave (timeout somewhere)
     unsigned long long epoch;        // bumped whenever the engine publishes something that may make a unit eligible: an idle workgroup
                                      // watches this word and the critical path's leaf counter instead of sweeping every claim word
-    unsigned long long pad[4];
+    unsigned long long xcc_wgs[8];   // workgroups of the engine that started on XCC x (counted at their start)
+    unsigned long long retired;      // workgroups that have left the chain's XCD for good (EngArgs::retire_leaf): the critical path waits for
+                                     // retired == xcc_wgs[that XCD] in front of its first XCD-local leaf
+    unsigned long long pad[3];
     EngCB cb[ENG_MAX_CB];
 };
 
@@ -227,11 +230,14 @@ struct EngArgs {
     int gemm_flags;
     long long* trace;   // measurement (RFLU_ENGINE_TRACE): per leaf g four wall-clock stamps of LEAF(g) on the column block of its first columns
     int x[8];       // experiment switches (Tune::engine_x)
+    int retire_xcc; // the workgroups on this XCC leave once retire_leaf leaves are done (-1: nobody retires): the short panels at the end, which
+    int retire_leaf; // the engine has little to do for, get the XCD their XCD-local exchange needs (driver.cpp: factor_leafwise)
 };
 
 template <typename T>
 int launch_engine(Handle* h, hipStream_t stream, const EngArgs<T>& a, int wgs);
 int launch_eng_wait(Handle* h, const unsigned long long* flag, unsigned long long value);
+int launch_eng_wait_retired(Handle* h, int xcc);   // the engine's workgroups on that XCC have all left
 size_t engine_lds_bytes(size_t esize);
 
 }  // namespace rflu

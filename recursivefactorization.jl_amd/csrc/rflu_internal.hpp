@@ -116,8 +116,10 @@ struct Tune {
     int engine = 0;                    // RFLU_ENGINE=1: the leaf-wise schedule's side / update stream work is pulled by the resident engine
     int engine_policy = 0;             // RFLU_ENGINE_POLICY: 0 = leftmost column block first, 1 = oldest panel piece first
     int engine_wgs = 0;                // RFLU_ENGINE_WGS: resident workgroups (0: two per CU of the update mask)
-    int64_t engine_rows = 4096;        // RFLU_ENGINE_ROWS: block columns whose panels are taller than this go through the engine
+    int64_t engine_rows = 0;           // RFLU_ENGINE_ROWS: block columns whose panels are taller than this go through the engine, the streams take over below (0: the engine
+                                       // to the end -- a hand-over waits for the engine's backlog on the far right: N=16384 79.6 ms at 4096 against 75.3)
     int engine_wc = 512;               // RFLU_ENGINE_WC: width of the engine's column blocks (a multiple of 128 dividing the block-column width; N=16384: 128: 82.7 ms, 256: 80.5, 512: 79.6)
+    int engine_retire = 1;             // RFLU_ENGINE_RETIRE=0: the engine's workgroups stay on the chain's XCD to the end (every leaf any-placement)
     int engine_host = 1;               // RFLU_ENGINE_HOST: host-pointer entry (rflu_getrf_*) through the engine: the way in overlaps the factorization
     int engine_x[8] = {0, 0, 1, 0, 0, 1, 16, 0};   // RFLU_ENGINE_X0..7 (engine.hip): X2 = 1: Schur tiles stored write-through (no L2 write-back per tile), X3: lag bound of the
                                        // host entry, X4 / X5 / X6: which workgroups serve the leaf windows only (default: 16 of XCD 1); X0 = 1 / X1 = 1: no release / acquire (timing only)

@@ -20,7 +20,7 @@ def _factor(n, dtype, pivot, blocksize, m=None, diag_add=0.0):
 
 
 @pytest.mark.parametrize("m,n,bs,dtype", [
-    (6144, 6144, 256, np.float64),       # default width of this size: engine for the panels above 4096 rows, streams below
+    (6144, 6144, 256, np.float64),       # default width of this size
     (8192, 8192, 512, np.float64),
     (10000, 10000, 0, np.float64),       # last leaf partial
     (10000, 6144, 512, np.float64),      # tall: every block column through the engine
@@ -55,12 +55,25 @@ def test_engine_nopivot_and_float32(monkeypatch):
     assert matvec_residual(A, F.factors, F.ipiv) < 20 * n * np.finfo(np.float32).eps
 
 
-def test_engine_down_to_short_panels(monkeypatch):
-    """RFLU_ENGINE_ROWS lowers the hand-over to the streams: more leaves (and their K = 64 windows) go through the engine."""
+@pytest.mark.parametrize("n,rows", [(6144, "1024"), (8192, "4096"), (12288, "4096")])
+def test_engine_hands_over_to_the_streams(n, rows, monkeypatch):
+    """RFLU_ENGINE_ROWS > 0: the streams take over at the first panel of at most that many rows (default 0: the engine to the end, its
+    workgroups on the chain's XCD retiring in front of the XCD-local short panels -- what test_engine_matches_stream_schedule runs)."""
     monkeypatch.setenv("RFLU_ENGINE", "0")
-    A, F = _factor(6144, np.float64, True, 0)
+    A, F = _factor(n, np.float64, True, 0)
     monkeypatch.setenv("RFLU_ENGINE", "1")
-    monkeypatch.setenv("RFLU_ENGINE_ROWS", "1024")
-    _, G = _factor(6144, np.float64, True, 0)
+    monkeypatch.setenv("RFLU_ENGINE_ROWS", rows)
+    _, G = _factor(n, np.float64, True, 0)
+    assert torch.equal(F.ipiv, G.ipiv)
+    assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
+
+
+def test_engine_without_retirement(monkeypatch):
+    """RFLU_ENGINE_RETIRE=0: the engine's workgroups stay everywhere to the end, every leaf any-placement."""
+    monkeypatch.setenv("RFLU_ENGINE", "0")
+    A, F = _factor(8192, np.float64, True, 0)
+    monkeypatch.setenv("RFLU_ENGINE", "1")
+    monkeypatch.setenv("RFLU_ENGINE_RETIRE", "0")
+    _, G = _factor(8192, np.float64, True, 0)
     assert torch.equal(F.ipiv, G.ipiv)
     assert matvec_residual(A, G.factors, G.ipiv) < 1e-12

@@ -1033,8 +1033,13 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         eng_retire_leaf = -1;
         a.retire_xcc = -1; a.retire_leaf = 0;
         {
-            const int64_t local_rows = restore_local.rows >= 0 ? restore_local.rows : (sizeof(T) == 4 ? 8192 : 4096);
-            if (h->tune.engine_retire && eng_end >= nblk && !h->eng_host_mode && f.pivot && h->panel_local == 2 && !h->coop_launch && local_rows >= 1024 && m > local_rows + 4 * NB) {
+            // (RFLU_ENGINE_RETIRE = the panel height from which on: at most what the XCD-local leaf is used for anyway)
+            const int64_t local_max = restore_local.rows >= 0 ? restore_local.rows : (sizeof(T) == 4 ? 8192 : 4096);
+            // (default -1: 4096 rows, 2048 from 16384 rows on, where the end is bound by the engine's throughput and its workgroups are worth
+            // more than the faster leaves for longer: N=16384 75.2-76.5 ms at 4096 / 74.4-75.2 at 2048, N=12288 44.8 / 47.1, N=8192 25.8 / 27.7)
+            const int64_t retire_rows = h->tune.engine_retire >= 0 ? h->tune.engine_retire : (m >= 16384 ? 2048 : 4096);
+            const int64_t local_rows = std::min<int64_t>(local_max, retire_rows);
+            if (retire_rows > 0 && eng_end >= nblk && !h->eng_host_mode && f.pivot && h->panel_local == 2 && !h->coop_launch && local_rows >= 1024 && m > local_rows + 4 * NB) {
                 eng_retire_leaf = (m - local_rows + NB - 1) / NB;   // first leaf whose panel has at most local_rows rows
                 a.retire_xcc = h->panel_xcc;
                 a.retire_leaf = (int)std::max<int64_t>(1, eng_retire_leaf - 2);
@@ -1105,7 +1110,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             const int64_t g = g0 + i, c0 = j0 + i * NB, w = std::min<int64_t>(NB, je - c0);
             if (in_eng && g == eng_retire_leaf) {   // the chain's XCD is its own again: XCD-local leaves from here on
                 RFLU_TRY(launch_eng_wait_retired(h, h->panel_xcc));
-                h->tune.panel_local_rows = restore_local.rows;
+                h->tune.panel_local_rows = restore_local.rows;   // (every panel from here on is at most engine_retire rows tall)
             }
             RFLU_TRY(launch_panel<T>(h, R, ld, m, c0, c0, w, f.ipiv, f.pivot));
             const int64_t la0 = c0 + w, la1 = std::min(la0 + NB, n);

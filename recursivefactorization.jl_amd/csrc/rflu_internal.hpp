@@ -119,7 +119,8 @@ struct Tune {
     int64_t engine_rows = 0;           // RFLU_ENGINE_ROWS: block columns whose panels are taller than this go through the engine, the streams take over below (0: the engine
                                        // to the end -- a hand-over waits for the engine's backlog on the far right: N=16384 79.6 ms at 4096 against 75.3)
     int engine_wc = 512;               // RFLU_ENGINE_WC: width of the engine's column blocks (a multiple of 128 dividing the block-column width; N=16384: 128: 82.7 ms, 256: 80.5, 512: 79.6)
-    int engine_retire = 1;             // RFLU_ENGINE_RETIRE=0: the engine's workgroups stay on the chain's XCD to the end (every leaf any-placement)
+    int engine_retire = -1;            // RFLU_ENGINE_RETIRE: from the first panel of at most this many rows on the engine's workgroups on the chain's XCD are gone and the
+                                       // leaves XCD-local (-1: 4096, 2048 for matrices of 16384 rows or more; 0: they stay to the end, every leaf any-placement)
     int engine_host = 1;               // RFLU_ENGINE_HOST: host-pointer entry (rflu_getrf_*) through the engine: the way in overlaps the factorization
     int engine_x[8] = {0, 0, 1, 0, 0, 1, 16, 0};   // RFLU_ENGINE_X0..7 (engine.hip): X2 = 1: Schur tiles stored write-through (no L2 write-back per tile), X3: lag bound of the
                                        // host entry, X4 / X5 / X6: which workgroups serve the leaf windows only (default: 16 of XCD 1); X0 = 1 / X1 = 1: no release / acquire (timing only)

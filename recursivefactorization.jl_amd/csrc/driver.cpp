@@ -508,7 +508,7 @@ static int validate_queues(Handle* h)
     double base = 0;
     RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));
     RFLU_TRY(queue_probe_rate(P, P, NPROBE, h->qprobe_slots, &base));   // the first pass warms the launch path
-    const double limit = std::max(2.0 * base, base + 5.0);   // base = the caller's stream against itself (3.1 us); a shared pipe reads 28
+    const double limit = std::min(std::max(2.0 * base, base + 5.0), 12.0);   // (a slow first reading of the base must not raise the bar to what a shared pipe reads)   // base = the caller's stream against itself (3.1 us); a shared pipe reads 28
     // a masked stream has to get along with the current caller stream and with the masked streams accepted before it.  (Not with the
     // caller streams it was accepted next to earlier: those are idle while this one is in use, and with two caller streams + three
     // masked streams there are more queues than pipes -- asking for that left the host entry's way-back stream on a shared pipe:
@@ -536,6 +536,15 @@ static int validate_queues(Handle* h)
             if (verbose)
                 fprintf(stderr, "[rflu] queue check %s[%d] attempt %d: %.1f us per kernel next to the accepted streams (alone %.1f)\n",
                         complement ? "pstream" : "ustream", r, attempt, worst, base);
+            if (worst <= limit) {
+                // a good reading is confirmed once: a colliding pair was seen to read low now and then (the whole process then runs with two
+                // queues on one pipe: N=8192 35 instead of 24 ms, N=16384 100 instead of 76 -- one process in a few dozen)
+                double again = 0;
+                RFLU_TRY(worst_next_to(*slot, &again));
+                if (verbose && again > limit)
+                    fprintf(stderr, "[rflu] queue check %s[%d] attempt %d: second reading %.1f us\n", complement ? "pstream" : "ustream", r, attempt, again);
+                worst = std::max(worst, again);
+            }
             if (worst <= limit) break;
             if (attempt == 7 || h->parked_streams.size() >= MAX_PARKED) {   // keep this one: never fail a factorization over placement
                 unresolved = true;

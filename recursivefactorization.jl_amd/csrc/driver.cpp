@@ -1057,9 +1057,9 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         a.trace = nullptr;
         static long long* eng_trace_buf = nullptr;   // measurement only (RFLU_ENGINE_TRACE=1): stamps of the leaf windows, printed at the next call
         if (env_str("RFLU_ENGINE_TRACE")) {
-            if (!eng_trace_buf) RFLU_HIP(hipMalloc((void**)&eng_trace_buf, 4096 * 4 * sizeof(long long)));
+            if (!eng_trace_buf) RFLU_HIP(hipMalloc((void**)&eng_trace_buf, (4096 * 4 + 8) * sizeof(long long)));
             else {
-                std::vector<long long> hs(4096 * 4);
+                std::vector<long long> hs(4096 * 4 + 8);
                 RFLU_HIP(hipMemcpy(hs.data(), eng_trace_buf, hs.size() * sizeof(long long), hipMemcpyDeviceToHost));
                 double s01 = 0, s12 = 0, s23 = 0, sq = 0; int cnt = 0;
                 for (int g = 1; g + 1 < (int)nleaf && g < 4095; ++g) {
@@ -1068,10 +1068,17 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                     sq += (hs[g * 4] - hs[(g - 1) * 4 + 3]) / 100.0; ++cnt;
                 }
                 if (cnt) fprintf(stderr, "[rflu] engine trace (previous call, %d leaf windows on their first column block): first claim -> stage 0 done %.1f us, -> first tile claimed %.1f, -> window complete %.1f; previous window complete -> first claim %.1f us\n", cnt, s01 / cnt, s12 / cnt, s23 / cnt, sq / cnt);
+                {
+                    const long long* ac = hs.data() + 4096 * 4;
+                    const double tot = (double)(ac[0] + ac[1] + ac[2] + ac[3] + ac[4]);
+                    if (tot > 0)
+                        fprintf(stderr, "[rflu] engine workgroup time (previous call, %.1f workgroup-ms): block-column tiles %.1f %%, leaf-window tiles %.1f %%, strips + solves %.1f %%, deferred interchanges %.1f %%, between units (scan, claim, wait, completion) %.1f %%\n",
+                                tot / 1e5, 100.0 * ac[0] / tot, 100.0 * ac[1] / tot, 100.0 * ac[2] / tot, 100.0 * ac[3] / tot, 100.0 * ac[4] / tot);
+                }
                 for (int g = 40; g < 44 && g + 1 < (int)nleaf; ++g)
                     fprintf(stderr, "   leaf %d: %.1f %.1f %.1f | since previous window complete %.1f\n", g, (hs[g * 4 + 1] - hs[g * 4]) / 100.0, (hs[g * 4 + 2] - hs[g * 4 + 1]) / 100.0, (hs[g * 4 + 3] - hs[g * 4 + 2]) / 100.0, (hs[g * 4] - hs[(g - 1) * 4 + 3]) / 100.0);
             }
-            RFLU_HIP(hipMemsetAsync(eng_trace_buf, 0, 4096 * 4 * sizeof(long long), P));
+            RFLU_HIP(hipMemsetAsync(eng_trace_buf, 0, (4096 * 4 + 8) * sizeof(long long), P));
             a.trace = eng_trace_buf;
         }
         // host entry: whole-block-column operations that lag the chain by this many block columns go first (engine.hip), so that

@@ -38,7 +38,7 @@
 namespace rflu {
 
 constexpr int EP_COLS = ENG_PREP_COLS;   // columns of a stage-0 unit
-constexpr int EP_XLD = EP_COLS + 16;    // LDS row pitch of the staged block (== 16 mod 32 doubles: conflict-free fragment reads)
+constexpr int EP_XLD = EP_COLS + 1;     // LDS row pitch of the staged block: odd -- the four k groups of a fragment read (rows 16 apart) land 16 doubles apart in the banks
 
 template <typename T>
 __device__ __forceinline__ int eng_units(const EngArgs<T>& a, int cb, unsigned seq)
@@ -151,14 +151,27 @@ __device__ __attribute__((noinline)) void eng_prep_unit(const EngUnit<T> a, cons
             }
         const bool rok = arow < rows_d;
         for (int e = 0; e < d; ++e) {
+            // (slot (fk, kk) of the MFMA stands for k = 16 fk + kk: a lane's 16 entries of L are 128 contiguous bytes of its row -- 16-byte
+            // loads -- where k = 4 kk + fk made them sixteen predicated 8-byte loads; the strips + solves were 10 % of the engine's time)
             T av[16], b0[16], b1[16];
-            const T* Lp = L + (int64_t)(d * NB + arow) * ld + e * NB + fk;
-            const T* Xe = B + (int64_t)(e * NB + fk) * ld + fi;
+            const T* Lp = L + (int64_t)(d * NB + arow) * ld + e * NB + 16 * fk;
+            const T* Xe = B + (int64_t)(e * NB + 16 * fk) * ld + fi;
+            if (rok) {
+                typedef T ep_vec __attribute__((ext_vector_type(VW)));
+#pragma unroll
+                for (int v = 0; v < 16 / VW; ++v) {
+                    const ep_vec x = *reinterpret_cast<const ep_vec*>(Lp + v * VW);
+#pragma unroll
+                    for (int q = 0; q < VW; ++q) av[v * VW + q] = -x[q];
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) av[kk] = T(0);
+            }
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                av[kk] = rok ? -Lp[kk * 4] : T(0);
-                b0[kk] = fi < nc ? Xe[(int64_t)(kk * 4) * ld] : T(0);
-                b1[kk] = 16 + fi < nc ? Xe[(int64_t)(kk * 4) * ld + 16] : T(0);
+                b0[kk] = fi < nc ? Xe[(int64_t)kk * ld] : T(0);
+                b1[kk] = 16 + fi < nc ? Xe[(int64_t)kk * ld + 16] : T(0);
             }
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
@@ -173,16 +186,21 @@ __device__ __attribute__((noinline)) void eng_prep_unit(const EngUnit<T> a, cons
             for (int r = 0; r < 4; ++r) Xd[(wave * 16 + Mfma<T>::crow(lane, r)) * EP_XLD + t * 16 + fi] = acc[t][r];
         T ai[16];
         {
-            const T* Ip = Linv + (int64_t)d * NB * NB + arow * NB + fk;
+            const T* Ip = Linv + (int64_t)d * NB * NB + arow * NB + 16 * fk;
+            typedef T ep_vec __attribute__((ext_vector_type(VW)));
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) ai[kk] = Ip[kk * 4];
+            for (int v = 0; v < 16 / VW; ++v) {
+                const ep_vec x = *reinterpret_cast<const ep_vec*>(Ip + v * VW);
+#pragma unroll
+                for (int q = 0; q < VW; ++q) ai[v * VW + q] = x[q];
+            }
         }
         __syncthreads();
         acc_t x[2] = {acc_t{T(0), T(0), T(0), T(0)}, acc_t{T(0), T(0), T(0), T(0)}};
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            const T q0 = Xd[(kk * 4 + fk) * EP_XLD + fi];
-            const T q1 = Xd[(kk * 4 + fk) * EP_XLD + 16 + fi];
+            const T q0 = Xd[(16 * fk + kk) * EP_XLD + fi];
+            const T q1 = Xd[(16 * fk + kk) * EP_XLD + 16 + fi];
             x[0] = Mfma<T>::run(ai[kk], q0, x[0]);
             x[1] = Mfma<T>::run(ai[kk], q1, x[1]);
         }
@@ -324,6 +342,10 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         return v > a.gate_base ? (int)(v - a.gate_base) : 0;
     };
 
+    // measurement (RFLU_ENGINE_TRACE): where a workgroup's time goes -- [0] whole-block-column tiles, [1] leaf-window tiles, [2] strips + solves,
+    // [3] deferred interchanges, [4] everything between two units (scan, claim, waiting, completion), summed over the workgroups
+    long long acct[5] = {0, 0, 0, 0, 0};
+    long long acct_t = a.trace ? wall_clock64() : 0;
     for (;;) {
         if (tid < 64) {
             int kind = ENG_NONE, sel_cb = 0, sel_unit = 0;
@@ -534,9 +556,12 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         __syncthreads();
         const int kind = s_sel[0], cb = s_sel[1], unit = s_sel[3];
         const unsigned seq = (unsigned)s_sel[2];
+        if (a.trace && tid == 0) { const long long t = wall_clock64(); acct[4] += t - acct_t; acct_t = t; }
         if (kind == ENG_EXIT) break;
+        int acct_k = 3;
         if (kind == ENG_MAIN) {
             const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+            acct_k = (seq & 1u) == 0 ? 2 : (o.type == ENG_OP_BIG ? 0 : 1);
             if (a.trace && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == (o.j0 + o.jb + NB) / a.g.Wc)
                 a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 2 : 0)] = wall_clock64();
             if ((seq & 1u) == 0) eng_prep_unit<T>(ua, o, unit);
@@ -546,6 +571,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         }
         // ---- completion: drain every wave's stores, one lane releases and counts ------------------------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.trace && tid == 0) { const long long t = wall_clock64(); acct[acct_k] += t - acct_t; acct_t = t; }
         __syncthreads();
         if (tid == 0) {
             // a Schur tile stored write-through has nothing left in this XCD's L2 (its stores are acknowledged: s_waitcnt above)
@@ -617,6 +643,8 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         }
         __syncthreads();
     }
+    if (a.trace && tid == 0)
+        for (int k = 0; k < 5; ++k) __hip_atomic_fetch_add((unsigned long long*)&a.trace[4096 * 4 + k], (unsigned long long)acct[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 size_t engine_lds_bytes(size_t esize)

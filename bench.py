@@ -418,6 +418,17 @@ def main():
                                         "(block-column lookahead, then leaf-wise): the bulk updates on the CU-masked stream "
                                         "(224 of 256 CUs) next to the critical path, with the clock the power management grants "
                                         "after the light phases (DESIGN.md section 7); sum of flops / sum of launch durations")
+            if g2["launches"] <= 2:
+                # the shipped schedule of this size runs its updates in ONE resident kernel (csrc/engine.hip: the persistent update engine,
+                # default for Float64 pivoted matrices of more than 12288 columns): that launch is the dominant kernel
+                roof["kernel"] = ("engine_kernel (persistent update engine: interchanges, block-row solves and every Schur tile "
+                                  "C -= A*B of the factorization, pulled from per-column-block counters; the tile code is gemm_sub_kernel's)")
+                roof["note_in_schedule"] = ("ONE launch: the engine is resident on 224 of 256 CUs for the whole factorization.  flops = the "
+                                            "Schur updates it performs (sum of 2 M N K over its operations), duration = its residency (HIP "
+                                            "event pair on its stream), i.e. waiting for the chain of leaves included -- RFLU_ENGINE_TRACE=1 "
+                                            "splits the workgroups' time (DESIGN.md section 3.12: tiles 59 + 8 %, strips and solves 6 %, "
+                                            "between units 26 %); the tile kernel by itself is frac_profiled")
+                roof["note"] = roof["note_in_schedule"] + "; " + roof["note"]
         if lw["launches"] > 0 and lw["ms"] > 0:
             tbs = lw["work"] / (lw["ms"] * 1e-3) / 1e12
             esz = 8 if sfx == "f64" else 4

@@ -861,7 +861,7 @@ template <typename T>
 static int engine_usable(const Handle* h, const Fact<T>& f, int64_t W)
 {
     constexpr int64_t VW = 16 / (int64_t)sizeof(T);
-    return (h->tune.engine != 0 || h->eng_host_mode) && W % 128 == 0 && f.roff == 0 && reinterpret_cast<uintptr_t>(f.R) % 16 == 0 && f.ld % VW == 0 &&
+    return W % 128 == 0 && f.roff == 0 && reinterpret_cast<uintptr_t>(f.R) % 16 == 0 && f.ld % VW == 0 &&
            f.m < (int64_t)1 << 30 && f.n < (int64_t)1 << 30 && (f.n + W - 1) / W <= ENG_MAX_CB && !h->progress && !h->mask_failed &&
            !h->tune.schedule_events && h->num_cus == 256 &&
            (f.m >= f.n || f.m % W == 0);   // (a fat matrix whose last panel ends inside a column block: the columns right of it in that block)
@@ -1085,7 +1085,25 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         // block rows become final -- and leave -- while the factorization runs (N=16384: 3: 123 ms, 5: 109-110, 8: 112, none: 118)
         if (h->eng_host_mode && a.x[3] == 0) a.x[3] = 5;
         const int wgs = h->tune.engine_wgs > 0 ? h->tune.engine_wgs : 2 * (h->num_cus - 32);
-        if (img->remaining > 0) RFLU_TRY(launch_engine<T>(h, E, a, wgs));
+        if (img->remaining > 0) {
+            // measurement (rflu_profile_enable(2)): the engine kernel as ONE launch of the class the bulk GEMM reports under -- its flops are
+            // the Schur updates it performs (every operation's 2 M N K), its duration the whole residency, waiting included
+            double eng_flops = 0;
+            for (int cb = 0; cb < geo.ncb; ++cb)
+                for (int k = 0; k < eng_nops(geo, cb); ++k) {
+                    const EngOp o = eng_op(geo, cb, k);
+                    eng_flops += 2.0 * (double)(geo.m - (o.j0 + o.jb)) * (double)o.nc * (double)o.jb;
+                }
+            hipStream_t saved = h->stream;
+            h->stream = E;
+            int rc;
+            {
+                ProfScope ps(h, RFLU_K_GEMM, eng_flops, sizeof(T) * (double)m * (double)n);
+                rc = launch_engine<T>(h, E, a, wgs);
+            }
+            h->stream = saved;
+            RFLU_TRY(rc);
+        }
         RFLU_TRY(record_on(E, evUend(eng_end - 1)));   // the engine leaves when every column block has received everything it owes
         h->eng_active = true;
         // While the engine is resident the only CUs with room are the 4 per XCD its mask leaves out: the any-placement leaves (at most
@@ -1346,7 +1364,13 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             // the update engine serves the block columns whose panels are taller than engine_rows (the leaf-wise schedule from block
             // column 0, its side / update streams replaced by the engine); below that the streams and the XCD-local leaves take over
             int64_t eng_end = 0;
-            if (leafwise && Wb >= 2 * NB && Wb <= 512 && W_wide == 0 && m <= 32 * (int64_t)PANEL_THREADS && engine_usable<T>(h, f, Wb)) {
+            // the engine where asked for (RFLU_ENGINE=1, the host entry) or, by default, where it measures faster than the streams: Float64
+            // with pivoting (a Float32 pivot search may answer the engine's other summation order with another pivot sequence, NoPivot with
+            // visibly other digits), the default block width of 512, i.e. more than 12288 columns (N=16384: 72 vs 75.5 ms; at 256-wide
+            // block columns the streams win: N=12288 44.7 vs 43.7, N=8192 25.7 vs 24.0)
+            const bool eng_wanted = h->eng_host_mode || h->tune.engine == 1 ||
+                                    (h->tune.engine < 0 && sizeof(T) == 8 && pivot && default_bs && Wb == 512 && mn > 12288 && m >= n);
+            if (eng_wanted && leafwise && Wb >= 2 * NB && Wb <= 512 && W_wide == 0 && m <= 32 * (int64_t)PANEL_THREADS && engine_usable<T>(h, f, Wb)) {
                 const int64_t er = h->eng_host_mode ? 0 : std::max<int64_t>(h->tune.engine_rows, 0);   // (host entry: every block column through the engine)
                 eng_end = m <= er ? 0 : std::min(nblk, (m - er + Wb - 1) / Wb);
             }

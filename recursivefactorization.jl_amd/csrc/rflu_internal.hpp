@@ -113,7 +113,8 @@ struct Tune {
     // participant that does not exist, runs into its bounded spin and raises the timeout flag (RFLU_ERR_TIMEOUT at the end)
     int debug_ghost_leaf = -1;         // RFLU_DEBUG_GHOST_LEAF
     // persistent update engine (engine.hip): an experiment of round 5 -- correct, measured slower than the stream schedules
-    int engine = 0;                    // RFLU_ENGINE=1: the leaf-wise schedule's side / update stream work is pulled by the resident engine
+    int engine = -1;                   // RFLU_ENGINE: 1 = the side / update streams' work is pulled by the resident engine wherever it can be, 0 = never,
+                                       // -1 (default) = where it measures faster: Float64, pivoted, default block width, 12288 < min(m, n), m <= 16384 (N=16384: 72 vs 75.5 ms)
     int engine_policy = 0;             // RFLU_ENGINE_POLICY: 0 = leftmost column block first, 1 = oldest panel piece first
     int engine_wgs = 0;                // RFLU_ENGINE_WGS: resident workgroups (0: two per CU of the update mask)
     int64_t engine_rows = 0;           // RFLU_ENGINE_ROWS: block columns whose panels are taller than this go through the engine, the streams take over below (0: the engine

@@ -1,5 +1,5 @@
-"""-m gpu: the persistent update engine (csrc/engine.hip, RFLU_ENGINE=1 -- an experiment of round 5, off by default: DESIGN.md
-section 9).  Every trailing update of the block columns with tall panels is pulled by resident workgroups from per-column-block
+"""-m gpu: the persistent update engine (csrc/engine.hip; RFLU_ENGINE=1 here -- by default it serves Float64 pivoted matrices of more than 12288
+columns and the host entry: DESIGN.md section 3.12).  Every trailing update of the block columns with tall panels is pulled by resident workgroups from per-column-block
 counters instead of being enqueued on the side / update streams; the eliminations and their order per column are those of the
 stream schedules (src/lu.jl:189-263, :265-284), so pivots must be identical and factors equal to rounding."""
 import numpy as np

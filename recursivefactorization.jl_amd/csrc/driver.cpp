@@ -1072,8 +1072,8 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                     const long long* ac = hs.data() + 4096 * 4;
                     const double tot = (double)(ac[0] + ac[1] + ac[2] + ac[3] + ac[4]);
                     if (tot > 0)
-                        fprintf(stderr, "[rflu] engine workgroup time (previous call, %.1f workgroup-ms): block-column tiles %.1f %%, leaf-window tiles %.1f %%, strips + solves %.1f %%, deferred interchanges %.1f %%, between units (scan, claim, wait, completion) %.1f %%\n",
-                                tot / 1e5, 100.0 * ac[0] / tot, 100.0 * ac[1] / tot, 100.0 * ac[2] / tot, 100.0 * ac[3] / tot, 100.0 * ac[4] / tot);
+                        fprintf(stderr, "[rflu] engine workgroup time (previous call, %.1f workgroup-ms): block-column tiles %.1f %%, leaf-window tiles %.1f %%, strips + solves %.1f %%, deferred interchanges %.1f %%, between units %.1f %% (of which asleep with nothing eligible %.1f %%, count + publication behind a unit %.1f %%, scan / claim / acquire %.1f %%)\n",
+                                tot / 1e5, 100.0 * ac[0] / tot, 100.0 * ac[1] / tot, 100.0 * ac[2] / tot, 100.0 * ac[3] / tot, 100.0 * ac[4] / tot, 100.0 * ac[5] / tot, 100.0 * ac[6] / tot, 100.0 * (ac[4] - ac[5] - ac[6]) / tot);
                 }
                 for (int g = 40; g < 44 && g + 1 < (int)nleaf; ++g)
                     fprintf(stderr, "   leaf %d: %.1f %.1f %.1f | since previous window complete %.1f\n", g, (hs[g * 4 + 1] - hs[g * 4]) / 100.0, (hs[g * 4 + 2] - hs[g * 4 + 1]) / 100.0, (hs[g * 4 + 3] - hs[g * 4 + 2]) / 100.0, (hs[g * 4] - hs[(g - 1) * 4 + 3]) / 100.0);

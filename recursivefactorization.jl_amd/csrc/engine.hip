@@ -344,7 +344,9 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
 
     // measurement (RFLU_ENGINE_TRACE): where a workgroup's time goes -- [0] whole-block-column tiles, [1] leaf-window tiles, [2] strips + solves,
     // [3] deferred interchanges, [4] everything between two units (scan, claim, waiting, completion), summed over the workgroups
-    long long acct[5] = {0, 0, 0, 0, 0};
+    int last_cb = -1;          // (wave 0) the stage this workgroup's last unit belonged to
+    unsigned last_seq = 0;
+    long long acct[7] = {0, 0, 0, 0, 0, 0, 0};   // ([6]: of [4], from the end of a unit to its count / publication being out)   // ([5]: of [4], the part spent asleep with nothing eligible)
     long long acct_t = a.trace ? wall_clock64() : 0;
     for (;;) {
         if (tid < 64) {
@@ -538,6 +540,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(32);
                         if (wall_clock64() - t0 > 400000000LL) { gave_up = true; break; }   // 4 s without any news: something upstream is stuck
                     }
+                    if (a.trace && tid == 0) acct[5] += wall_clock64() - t0;
                     if (gave_up) {
                         if (lane == 0) {
                             __hip_atomic_fetch_or((unsigned long long*)(a.info + 1), 17ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -549,9 +552,15 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 }
             }
             if (lane == 0) {
-                if ((kind == ENG_MAIN || kind == ENG_LEFT) && !(a.x[1] & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // the acquire (an L1 invalidate) once per (column block, sequence): everything a tile of a stage reads was final when the
+                // stage was published, and the tiles other workgroups write during it are not read by this one -- the second and later
+                // tiles of the same stage keep their L1 (the U12 strip they share) and save the fence
+                const bool same_stage = kind == ENG_MAIN && (sel_seq & 1u) != 0 && sel_cb == last_cb && sel_seq == last_seq;
+                if ((kind == ENG_MAIN || kind == ENG_LEFT) && !(a.x[1] & 1) && !same_stage) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 s_sel[0] = kind; s_sel[1] = sel_cb; s_sel[2] = (int)sel_seq; s_sel[3] = sel_unit;
             }
+            // (all lanes of the wave: the values are wave-uniform)
+            if (kind == ENG_MAIN) { last_cb = sel_cb; last_seq = sel_seq; } else { last_cb = -1; }
         }
         __syncthreads();
         const int kind = s_sel[0], cb = s_sel[1], unit = s_sel[3];
@@ -641,10 +650,11 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 }
             }
         }
+        if (a.trace && tid == 0) acct[6] += wall_clock64() - acct_t;
         __syncthreads();
     }
     if (a.trace && tid == 0)
-        for (int k = 0; k < 5; ++k) __hip_atomic_fetch_add((unsigned long long*)&a.trace[4096 * 4 + k], (unsigned long long)acct[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 7; ++k) __hip_atomic_fetch_add((unsigned long long*)&a.trace[4096 * 4 + k], (unsigned long long)acct[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 size_t engine_lds_bytes(size_t esize)

@@ -428,7 +428,12 @@ def main():
                                             "event pair on its stream), i.e. waiting for the chain of leaves included -- RFLU_ENGINE_TRACE=1 "
                                             "splits the workgroups' time (DESIGN.md section 3.12: tiles 59 + 8 %, strips and solves 6 %, "
                                             "between units 26 %); the tile kernel by itself is frac_profiled")
-                roof["note"] = roof["note_in_schedule"] + "; " + roof["note"]
+                # HBM traffic: the PMC figure under profiles/ belongs to the bulk tile kernel of the profiled pass (per gemm_sub_kernel launch);
+                # counter collection runs one kernel at a time, which a resident kernel that waits for the chain's kernels cannot survive
+                roof["traffic_profiled"] = roof.get("traffic")
+                roof["traffic"] = None
+                roof["note"] = (roof["note_in_schedule"] + "; traffic: null for the resident kernel (rocprofv3 --pmc serialises kernels; "
+                                "traffic_profiled = HBM bytes per launch of the tile kernel in the profiled pass); " + roof["note"])
         if lw["launches"] > 0 and lw["ms"] > 0:
             tbs = lw["work"] / (lw["ms"] * 1e-3) / 1e12
             esz = 8 if sfx == "f64" else 4

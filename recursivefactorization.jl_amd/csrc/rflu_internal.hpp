@@ -112,7 +112,7 @@ struct Tune {
     // fault injection (tests): the cooperative leaf launch with this sequence number inside a factorization waits for a
     // participant that does not exist, runs into its bounded spin and raises the timeout flag (RFLU_ERR_TIMEOUT at the end)
     int debug_ghost_leaf = -1;         // RFLU_DEBUG_GHOST_LEAF
-    // persistent update engine (engine.hip): an experiment of round 5 -- correct, measured slower than the stream schedules
+    // persistent update engine (engine.hip): the default schedule where it measures faster than the streams, and the host entry
     int engine = -1;                   // RFLU_ENGINE: 1 = the side / update streams' work is pulled by the resident engine wherever it can be, 0 = never,
                                        // -1 (default) = where it measures faster: Float64, pivoted, default block width, 12288 < min(m, n), m <= 16384 (N=16384: 72 vs 75.5 ms)
     int engine_policy = 0;             // RFLU_ENGINE_POLICY: 0 = leftmost column block first, 1 = oldest panel piece first

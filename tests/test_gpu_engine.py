@@ -77,3 +77,20 @@ def test_engine_without_retirement(monkeypatch):
     _, G = _factor(8192, np.float64, True, 0)
     assert torch.equal(F.ipiv, G.ipiv)
     assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
+
+
+@pytest.mark.parametrize("m,n", [(13000, 13000), (16384, 12800), (16000, 15000)])
+def test_default_rule_sends_these_shapes_through_the_engine(m, n, monkeypatch):
+    """RFLU_ENGINE unset: Float64 pivoted matrices of more than 12288 columns (default block width, at most 16384 rows, not fat) are
+    factored through the engine; pivots equal to the stream schedule's (RFLU_ENGINE=0), factors equal to rounding."""
+    monkeypatch.setenv("RFLU_ENGINE", "0")
+    A, F = _factor(n, np.float64, True, 0, m=m)
+    monkeypatch.delenv("RFLU_ENGINE")
+    _, G = _factor(n, np.float64, True, 0, m=m)
+    assert F.info == G.info == 0
+    assert torch.equal(F.ipiv, G.ipiv)
+    scale = float(F.factors.abs().max())
+    d = float((F.factors - G.factors).abs().max())
+    assert 0.0 < d <= 1e-10 * scale   # (not bit-identical: another summation order, i.e. the engine did run)
+    if m == n:
+        assert matvec_residual(A, G.factors, G.ipiv) < 1e-12

@@ -42,7 +42,13 @@ enum rflu_status {
 
 /* rflu_last_path values: which implementation served the last getrf call on this handle.  The analogue of the
  * reference's dispatch-routing tests (test/runtests.jl:86-114,162-192): tests assert the HIP path really ran. */
-enum rflu_path { RFLU_PATH_NONE = 0, RFLU_PATH_HIP_RECURSIVE = 1, RFLU_PATH_HIP_BLOCKED = 2, RFLU_PATH_HIP_LOOKAHEAD = 3 };
+enum rflu_path {
+    RFLU_PATH_NONE = 0,
+    RFLU_PATH_HIP_RECURSIVE = 1, /* pure Toledo recursion on one stream */
+    RFLU_PATH_HIP_BLOCKED = 2,   /* right-looking block columns on one stream (profiling modes, devices without 256 CUs) */
+    RFLU_PATH_HIP_LOOKAHEAD = 3, /* block-column lookahead / leaf-wise schedules on CU-masked streams */
+    RFLU_PATH_HIP_ENGINE = 4     /* the leaf-wise chain with every trailing update pulled by the persistent update engine (csrc/engine.hip) */
+};
 
 /* kernel classes for the built-in per-kernel timers (rflu_profile_*) */
 enum rflu_kclass {

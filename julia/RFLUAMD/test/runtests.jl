@@ -17,7 +17,7 @@ end
             A = rand(T, s, m)
             _p || (A = A + T(10) * Matrix{T}(I, s, m))          # the reference's NoPivot inputs are diagonally shifted
             MF = RFLUAMD.lu(A, Val(_p))
-            RFLUAMD.available() && @test RFLUAMD.last_path() in (1, 3)
+            RFLUAMD.available() && @test RFLUAMD.last_path() in (1, 3, 4)
             testlu(A, MF, baselu(A, _p ? RowMaximum() : NoPivot()), _p)
             At = permutedims(A)
             testlu(At, parent(RFLUAMD.lu(At', Val(_p))), baselu(At, _p ? RowMaximum() : NoPivot()), _p)

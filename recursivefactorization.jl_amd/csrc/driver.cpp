@@ -867,6 +867,23 @@ static int engine_usable(const Handle* h, const Fact<T>& f, int64_t W)
            (f.m >= f.n || f.m % W == 0);   // (a fat matrix whose last panel ends inside a column block: the columns right of it in that block)
 }
 
+// the engine's state block (device) and the pinned host image of its initial value: both or neither (a half-made pair would
+// have the next call write its image through a null pointer); freed by rflu_destroy
+static int ensure_engine_state(Handle* h)
+{
+    if (h->eng_state && h->eng_host) return RFLU_OK;
+    if (!h->eng_host) RFLU_HIP(hipHostMalloc(&h->eng_host, sizeof(EngState), hipHostMallocDefault));
+    if (!h->eng_state) {
+        if (hipMalloc(&h->eng_state, sizeof(EngState)) != hipSuccess) {
+            (void)hipGetLastError();
+            h->eng_state = nullptr;
+            set_error("hipMalloc of the update engine's state failed");
+            return RFLU_ERR_HIP;
+        }
+    }
+    return RFLU_OK;
+}
+
 // Leaf-wise schedule: the critical path is nothing but the chain of cooperative leaves.
 //
 // The recursion's merges (solve + Schur update of the right half) and the block-column lookahead put ~640 us of small
@@ -995,10 +1012,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         if (b_begin != 0) { set_error("factor_leafwise: the engine starts at block column 0"); return RFLU_ERR_ARG; }
         eng_end = std::min(eng_end, nblk);
         RFLU_TRY(get_ustream(h, 32, &E));
-        if (!h->eng_state) {
-            RFLU_HIP(hipMalloc(&h->eng_state, sizeof(EngState)));
-            RFLU_HIP(hipHostMalloc(&h->eng_host, sizeof(EngState), hipHostMallocDefault));
-        }
+        RFLU_TRY(ensure_engine_state(h));
         est = static_cast<EngState*>(h->eng_state);
         EngState* img = static_cast<EngState*>(h->eng_host);
         geo.m = (int)m; geo.n = (int)n; geo.mn = (int)mn; geo.W = (int)W; geo.nbp = (int)eng_end;
@@ -1055,7 +1069,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             }
         }
         a.trace = nullptr;
-        static long long* eng_trace_buf = nullptr;   // measurement only (RFLU_ENGINE_TRACE=1): stamps of the leaf windows, printed at the next call
+        long long*& eng_trace_buf = h->eng_trace_buf;   // measurement only (RFLU_ENGINE_TRACE=1): stamps of the leaf windows, printed at the next call
         if (env_str("RFLU_ENGINE_TRACE")) {
             if (!eng_trace_buf) RFLU_HIP(hipMalloc((void**)&eng_trace_buf, (4096 * 4 + 8) * sizeof(long long)));
             else {
@@ -1204,6 +1218,16 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                 // (Round 4 tried leaving the next block column's part of the first 1..6 leaves to a later leaf, so that the in-order
                 // side stream does not sit on the event with the own parts of the next leaves queued behind it: no gain, N=16384
                 // 78.2-78.9 vs 78.7-79.1 ms -- the event is not what the side stream waits for, see swap_mode above.)
+                if (eng_end > 0 && b == eng_end) {
+                    // hand-over from the update engine: the rest of THIS block column is the side stream's from here on, and the engine may
+                    // still be applying the previous block column's last leaves to it (the chain's wait covered the first tile column of the
+                    // lookahead strip's column block only): every column block of block column b must have completed its sequence
+                    for (int c = eng_first_cb(geo, (int)b); rc == RFLU_OK && c < eng_first_cb(geo, (int)b) + eng_cbs_of_block(geo, (int)b); ++c)
+                        if (eng_nops(geo, c) > 0) {
+                            h->stream = S;
+                            rc = launch_eng_wait(h, &est->cb[c].prog, 2ull * (unsigned long long)eng_nops(geo, c));
+                        }
+                }
                 if (rc == RFLU_OK) rc = apply_leaf(S, c0, w, la1, bend, true);
                 h->stream = S;
                 if (rc == RFLU_OK) rc = launch_gate_signal(h, h->gate_ptr[1], val(g), stamp(1, g));
@@ -1384,6 +1408,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             }
             f.tail = tail;
             if (eng_end > 0) {
+                h->last_path = RFLU_PATH_HIP_ENGINE;
                 RFLU_TRY(factor_leafwise<T>(f, Wb, 0, nullptr, eng_end));
                 b_switch = nblk;
             } else if (b_switch > 0) RFLU_TRY(factor_lookahead<T>(f, Wb, b_switch, &U_last, W_wide, wide_end));
@@ -1538,10 +1563,7 @@ static int getrf_host_engine(Handle* h, int64_t m, int64_t n, T* A, int64_t lda,
             }
         h->bounce_bytes = bounce_bytes;
     }
-    if (!h->eng_state) {
-        RFLU_HIP(hipMalloc(&h->eng_state, sizeof(EngState)));
-        RFLU_HIP(hipHostMalloc(&h->eng_host, sizeof(EngState), hipHostMallocDefault));
-    }
+    RFLU_TRY(ensure_engine_state(h));
     if (!h->eng_rows_final) {
         void* p = nullptr;
         if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return RFLU_OK; }
@@ -2033,6 +2055,10 @@ int rflu_destroy(rflu_handle_t handle)
     if (h->tail_event_obj) (void)hipEventDestroy(h->tail_event_obj);
     if (h->tail_fork_obj) (void)hipEventDestroy(h->tail_fork_obj);
     if (h->gate_stamps) (void)hipFree(h->gate_stamps);
+    if (h->eng_state) (void)hipFree(h->eng_state);
+    if (h->eng_host) (void)hipHostFree(h->eng_host);
+    if (h->eng_rows_final) (void)hipHostFree(h->eng_rows_final);
+    if (h->eng_trace_buf) (void)hipFree(h->eng_trace_buf);
     if (h->info_pinned) (void)hipHostFree(h->info_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -598,7 +598,9 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 if (first_col && (int)(dd >> 32) == tiles_m && (int)d != units) {
                     // the window's first tile column is complete: the critical path may go on (prog = 2 * completed ops + 1)
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                    __hip_atomic_store(&c->prog, 2ull * (unsigned long long)(seq >> 1) + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    // (a maximum, not a store: the workgroup that completes the whole sequence may publish 2 * (op + 1) BEFORE this one, delayed
+                    // between its count and this line, gets here -- a plain store would take the word back to 2 * op + 1 for good)
+                    __hip_atomic_fetch_max(&c->prog, 2ull * (unsigned long long)(seq >> 1) + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if ((int)d == units) {
                     if (a.trace && o.type == ENG_OP_LEAF && cb == (o.j0 + o.jb + NB) / a.g.Wc)
@@ -615,7 +617,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                         for (unsigned k = seq >> 1; k < (ns >> 1); ++k)   // (the operations just completed, skipped ones included)
                             if ((int)k < eng_nbig(a.g, cb))
                                 __hip_atomic_fetch_add(&st->cb[eng_first_cb(a.g, (int)k)].bigdone, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&c->prog, 2ull * (unsigned long long)(ns >> 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_max(&c->prog, 2ull * (unsigned long long)(ns >> 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (ns >= end) {
                         __hip_atomic_store(&c->claim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

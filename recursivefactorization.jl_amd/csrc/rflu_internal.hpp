@@ -204,9 +204,9 @@ struct Handle {
                                  // bit-identical, measured no faster than the default leaves: opt-in)
     int panel_local_maxg = 64;
     int panel_xcc = 0;
-    int trsv_max_wgs = 0;        // same for the cooperative solve kernels (asked on first use)
-    int trsm32_per_cu = 0;
-    int trsm16_per_cu = 0;       // workgroups of the 16-column block solve a CU holds (trsv.hip: chains side by side)
+    int trsv_max_wgs[2] = {0, 0};    // same for the cooperative solve kernels (asked on first use, per element type: [Float64, Float32])
+    int trsm32_per_cu[2] = {0, 0};
+    int trsm16_per_cu[2] = {0, 0};   // workgroups of the 16-column block solve a CU holds (trsv.hip: chains side by side)
     int panel_max_wgs = 0;       // how many workgroups of the cooperative panel kernels the device holds at once (occupancy query)
     bool coop_launch = false;    // RFLU_COOP_LAUNCH=1: hipLaunchCooperativeKernel (launch-time residency check, +15-19 us each)
     bool la_attr_set[2] = {false, false};     // dynamic-LDS opt-in of leaf_la_kernel (f64, f32)
@@ -214,6 +214,7 @@ struct Handle {
     bool eng_attr_set[2] = {false, false};    // same for the persistent update engine (engine.hip)
     void* eng_state = nullptr;                // device: EngState (engine.hpp)
     void* eng_host = nullptr;                 // pinned host image of its initial value
+    long long* eng_trace_buf = nullptr;       // device: RFLU_ENGINE_TRACE stamps + workgroup-time accounting (measurement only)
     bool eng_active = false;                  // a factorization's engine is resident (factor_leafwise in engine mode .. the join with its stream)
     // host entry through the engine (driver.cpp: getrf_host_engine): the matrix arrives while it is being factored
     bool eng_host_mode = false;

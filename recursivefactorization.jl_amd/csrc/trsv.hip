@@ -862,7 +862,8 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
     }
     const unsigned grid = (unsigned)std::min<int64_t>(nb, TV_MAX_WGS);
     {   // the stages wait for each other's results: every workgroup of a launch must be resident (asked once per handle)
-        if (h->trsv_max_wgs == 0) {
+        constexpr int TI = sizeof(T) == 8 ? 0 : 1;   // per element type: the Float64 kernels hold twice the LDS of the Float32 ones
+        if (h->trsv_max_wgs[TI] == 0) {
             int a = 0, b = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&trsv_chain_kernel<T, false, TV_NR>), TV_THREADS, 0) != hipSuccess ||
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&trsv_chain_kernel<T, true, TV_NR>), TV_THREADS, 0) != hipSuccess) {
@@ -881,21 +882,26 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
                 (void)hipGetLastError();
                 e = f = 0;
             }
-            h->trsm16_per_cu = std::min(e, f);
+            h->trsm16_per_cu[TI] = std::min(e, f);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, reinterpret_cast<const void*>(&trsm_chain_kernel<T, false, 32, 1>), TV_THREADS, 0) != hipSuccess ||
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, reinterpret_cast<const void*>(&trsm_chain_kernel<T, true, 32, 1>), TV_THREADS, 0) != hipSuccess) {
                 (void)hipGetLastError();
                 e = f = 0;
             }
-            h->trsm32_per_cu = std::min(e, f);
-            h->trsv_max_wgs = std::max(1, std::min(std::min(a, b), std::min(c, d)) * h->num_cus);
+            h->trsm32_per_cu[TI] = std::min(e, f);
+            h->trsv_max_wgs[TI] = std::max(1, std::min(std::min(a, b), std::min(c, d)) * h->num_cus);
         }
-        if ((int)grid > h->trsv_max_wgs) {
-            set_error("launch_trsv_coop: %u cooperating workgroups, but the device holds %d at a time", grid, h->trsv_max_wgs);
+        if ((int)grid > h->trsv_max_wgs[TI]) {
+            set_error("launch_trsv_coop: %u cooperating workgroups, but the device holds %d at a time", grid, h->trsv_max_wgs[TI]);
             return RFLU_ERR_ARG;
         }
     }
-    static const int dbg_skip = getenv("RFLU_DBG_SOLVE_SKIP") ? atoi(getenv("RFLU_DBG_SOLVE_SKIP")) : 0;   // timing only: 1 = no chain kernels, 2 = L only, 3 = U only
+#ifdef RFLU_EXPERIMENTS
+    // experiments build only (it returns RFLU_OK with B unsolved): timing of the preparation kernels / one triangle alone
+    static const int dbg_skip = getenv("RFLU_DBG_SOLVE_SKIP") ? atoi(getenv("RFLU_DBG_SOLVE_SKIP")) : 0;   // 1 = no chain kernels, 2 = L only, 3 = U only
+#else
+    constexpr int dbg_skip = 0;
+#endif
     if (wide && dbg_skip == 1) return RFLU_OK;
     if (wide) {
         // a pass of up to 64 columns as ONE chain of 64, TWO of 32 or FOUR of 16 columns side by side (trsm_chain_kernel); the narrower
@@ -906,7 +912,7 @@ int launch_trsv_coop(Handle* h, int64_t n, int64_t nrhs, const T* R, int64_t ld,
             const int nrc = mode == 1 ? 16 : mode == 2 ? 32 : TC_NR;
             const int chains = (nr + nrc - 1) / nrc;
             const int run = mode == 1 ? 2 : 1;
-            const int per_cu = mode == 1 ? h->trsm16_per_cu : mode == 2 ? h->trsm32_per_cu : 1;
+            const int per_cu = mode == 1 ? h->trsm16_per_cu[sizeof(T) == 8 ? 0 : 1] : mode == 2 ? h->trsm32_per_cu[sizeof(T) == 8 ? 0 : 1] : 1;
             const int64_t want = (nb + run - 1) / run;
             const int g = (int)std::min<int64_t>(want, (int64_t)per_cu * h->num_cus / chains);
             const bool split = mode != 0 && per_cu > 0 && (g >= 32 || g == want);

@@ -311,5 +311,6 @@ def ldiv_(F: LU, B, *, handle=None):
 
 
 def last_path(device: int = 0) -> str:
-    """Which implementation served the last factorization on ``device`` ("hip-recursive" / "hip-blocked" / "none")."""
-    return {0: "none", 1: "hip-recursive", 2: "hip-blocked", 3: "hip-lookahead"}[_ffi.default_handle(device).last_path()]
+    """Which implementation served the last factorization on ``device`` (``enum rflu_path`` of include/rflu.h: "hip-recursive" /
+    "hip-blocked" / "hip-lookahead" / "hip-engine" / "none")."""
+    return {0: "none", 1: "hip-recursive", 2: "hip-blocked", 3: "hip-lookahead", 4: "hip-engine"}[_ffi.default_handle(device).last_path()]

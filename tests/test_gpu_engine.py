@@ -35,7 +35,7 @@ def test_engine_matches_stream_schedule(m, n, bs, dtype, monkeypatch):
         monkeypatch.setenv("RFLU_ENGINE_POLICY", policy)
         _, G = _factor(n, dtype, True, bs, m=m)
         assert F.info == G.info == 0
-        assert rf.last_path() == "hip-lookahead"
+        assert rf.last_path() == "hip-engine"
         assert torch.equal(F.ipiv, G.ipiv)
         scale = float(F.factors.abs().max())
         assert float((F.factors - G.factors).abs().max()) <= 1e-10 * scale
@@ -85,12 +85,42 @@ def test_default_rule_sends_these_shapes_through_the_engine(m, n, monkeypatch):
     factored through the engine; pivots equal to the stream schedule's (RFLU_ENGINE=0), factors equal to rounding."""
     monkeypatch.setenv("RFLU_ENGINE", "0")
     A, F = _factor(n, np.float64, True, 0, m=m)
+    assert rf.last_path() == "hip-lookahead"
     monkeypatch.delenv("RFLU_ENGINE")
     _, G = _factor(n, np.float64, True, 0, m=m)
+    assert rf.last_path() == "hip-engine"
     assert F.info == G.info == 0
     assert torch.equal(F.ipiv, G.ipiv)
     scale = float(F.factors.abs().max())
     d = float((F.factors - G.factors).abs().max())
-    assert 0.0 < d <= 1e-10 * scale   # (not bit-identical: another summation order, i.e. the engine did run)
+    assert d <= 1e-10 * scale
     if m == n:
         assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
+
+
+@pytest.mark.parametrize("m,n,bs", [(6144, 6144, 256), (8192, 8192, 512), (10000, 6144, 512)])
+def test_engine_against_the_cpu_oracle(m, n, bs, monkeypatch):
+    """The engine against the ORACLE (not against the stream schedules of the same library): `ipiv` and `info` bit-exact, factors within
+    50 E max|LU| of the CPU restatement of src/lu.jl:189-338 on the same input (E = 20 s eps, test/runtests.jl:19-20), residual below E."""
+    import os
+    import oracle as O
+    O.use_native()
+    O.set_threads(min(64, os.cpu_count() or 1))
+    try:
+        A = O.fill_uniform(m, n, 40 + m + n, np.float64)
+        Fo, ipo, info_o = O.lu(A)
+    finally:
+        O.set_threads(1)
+    assert info_o == 0
+    monkeypatch.setenv("RFLU_ENGINE", "1")
+    W = torch.from_numpy(np.ascontiguousarray(A.T)).to("cuda:0").T      # column-major device view
+    F = rf.lu_(W, None, True, check=False, blocksize=bs)
+    assert rf.last_path() == "hip-engine" and F.info == 0
+    ip = F.ipiv.cpu().numpy()
+    assert np.array_equal(ip, ipo), f"first difference from the CPU path at pivot {int(np.argmax(ip != ipo))}"
+    got = F.factors.cpu().numpy()
+    E = 20 * min(m, n) * np.finfo(np.float64).eps
+    assert float(np.abs(got - Fo).max()) <= 50 * E * max(1.0, float(np.abs(Fo).max()))
+    if m == n:
+        dA = torch.from_numpy(np.ascontiguousarray(A.T)).to("cuda:0").T   # (W was factored in place)
+        assert matvec_residual(dA, F.factors, F.ipiv) < 1e-12

@@ -57,6 +57,24 @@ def test_host_entry_matches_device_entry(m, n, dtype, pivot, bs, monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_host_entry_headline_size_through_the_engine():
+    """n = 16384 Float64 pivoted, the size `host_entry` of the bench line is quoted on: the matrix arrives block column by block column
+    while the engine factors what is there (getrf_host_engine), block rows go home as they become final -- pivots and info equal to
+    the device entry's, factors equal to rounding (the device entry of this size runs the same engine: same summation order per column
+    block, but which workgroup finishes a tile first is not fixed, so `equal to rounding`, not `to the bit`)."""
+    n = 16384
+    A = O.fill_uniform(n, n, 12, np.float64)
+    ref, ipr, infr = _device_reference(A, True, None)
+    assert rf.last_path() == "hip-engine" and infr == 0
+    H = np.asfortranarray(A)
+    del A
+    F = rf.lu_(H, None, True, check=False)
+    assert rf.last_path() == "hip-engine"
+    assert F.info == 0
+    assert np.array_equal(np.asarray(F.ipiv), ipr)
+    assert np.abs(np.asarray(F.factors) - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
 def test_host_entry_with_a_column_stride_and_reuse():
     """lda > m (a view into a taller buffer), the same handle and bounce buffers used for a second, smaller matrix."""
     n, lda = 8192, 8192 + 24

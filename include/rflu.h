@@ -86,6 +86,10 @@ int rflu_debug_heat(rflu_handle_t handle, double usec);
 /* Measurement aid (scripts/gate_trace.py): with RFLU_GATE_TRACE=1 in the environment the leaf-wise schedule stamps the wall
  * clock (100 MHz ticks) when each stream passes each leaf; copies the 3 x 4096 stamps to `out` (host). */
 int rflu_debug_gate_stamps(rflu_handle_t handle, long long* out);
+/* RFLU_ENGINE_TRACE=1 (measurement): workgroup-time accumulators of the last launch of the persistent update engine on this handle, in
+ * 100 MHz ticks summed over its workgroups: out8[0] block-column tiles, [1] leaf-window tiles, [2] interchange strips + block-row solves,
+ * [3] deferred interchanges on finished columns, [4] everything between two units, [5] (part of 4) asleep, [6] (part of 4) publications */
+int rflu_debug_engine_acct(rflu_handle_t handle, long long* out8);
 
 /* ---- the boundary: lu!(A, ipiv, pivot; blocksize) on HOST buffers (caller-owned, column-major) ----
  * Replaces src/lu.jl:114-126 (recursive path + unblocked fallback) for Float64 / Float32.

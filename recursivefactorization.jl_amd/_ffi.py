@@ -52,6 +52,7 @@ _PLAIN = {
     "rflu_update_stream": (c_int, [c_p, ctypes.POINTER(c_p)]),
     "rflu_debug_heat": (c_int, [c_p, ctypes.c_double]),
     "rflu_debug_gate_stamps": (c_int, [c_p, c_p]),
+    "rflu_debug_engine_acct": (c_int, [c_p, c_p]),
     "rflu_mgpu_create": (c_int, [ctypes.POINTER(c_p), c_int, ctypes.POINTER(c_int)]),
     "rflu_mgpu_reload_tuning": (c_int, [c_p]),
     "rflu_mgpu_destroy": (c_int, [c_p]),

@@ -111,13 +111,14 @@ void Tune::load_env()
     env_get("RFLU_ENGINE_WGS", engine_wgs);
     env_get("RFLU_ENGINE_ROWS", engine_rows);
     env_get("RFLU_ENGINE_HOST", engine_host);
+    env_get("RFLU_ENGINE_REPLAY", engine_replay);
     env_get("RFLU_ENGINE_WC", engine_wc);
     env_get("RFLU_ENGINE_RETIRE", engine_retire);
-    for (int i = 0; i < 8; ++i) {
-        char name[32];
-        snprintf(name, sizeof(name), "RFLU_ENGINE_X%d", i);
-        env_get(name, engine_x[i]);
-    }
+    env_get("RFLU_ENGINE_WRITE_THROUGH", engine_write_through);
+    env_get("RFLU_ENGINE_LEAF_XCDS", engine_leaf_xcds);
+    env_get("RFLU_ENGINE_LEAF_WGS", engine_leaf_wgs);
+    env_get("RFLU_ENGINE_HOST_LAG", engine_host_lag);
+    env_get("RFLU_ENGINE_AHEAD", engine_ahead);
 }
 
 // the handle's own switches (kernel routing) + its Tune
@@ -863,7 +864,7 @@ static int engine_usable(const Handle* h, const Fact<T>& f, int64_t W)
     constexpr int64_t VW = 16 / (int64_t)sizeof(T);
     return W % 128 == 0 && f.roff == 0 && reinterpret_cast<uintptr_t>(f.R) % 16 == 0 && f.ld % VW == 0 &&
            f.m < (int64_t)1 << 30 && f.n < (int64_t)1 << 30 && (f.n + W - 1) / W <= ENG_MAX_CB && !h->progress && !h->mask_failed &&
-           !h->tune.schedule_events && h->num_cus == 256 &&
+           (!h->tune.schedule_events || h->tune.engine_replay) && h->num_cus == 256 &&
            (f.m >= f.n || f.m % W == 0);   // (a fat matrix whose last panel ends inside a column block: the columns right of it in that block)
 }
 
@@ -1019,6 +1020,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         geo.Wc = (h->tune.engine_wc >= 128 && h->tune.engine_wc % 128 == 0 && W % h->tune.engine_wc == 0) ? h->tune.engine_wc : (int)W;
         geo.ncb = (int)((n + geo.Wc - 1) / geo.Wc);
         geo.pivot = f.pivot;
+        geo.ahead = std::max(1, std::min(h->tune.engine_ahead, 4));
         if (geo.ncb > ENG_MAX_CB) { geo.Wc = (int)W; geo.ncb = (int)((n + W - 1) / W); }
         const size_t bytes = offsetof(EngState, cb) + (size_t)geo.ncb * sizeof(EngCB);
         const size_t skip = offsetof(EngState, remaining);   // (the arrival word in front belongs to the feeding stream: getrf_host_engine)
@@ -1039,6 +1041,11 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             if (nleft > 0 && lk > 0) img->cb[eng_first_cb(geo, eng_pb(geo, cb))].leftdone += 1ull << 32;   // ... towards the block column's own count too
             img->remaining += lk < nleft;
         }
+        if (h->tune.engine_replay) {   // measurement: every leaf counts as done before the engine starts (the chain below is skipped)
+            if (eng_end < nblk) { set_error("RFLU_ENGINE_REPLAY needs the engine to the end"); return RFLU_ERR_ARG; }
+            RFLU_TRY(launch_gate_signal(h, h->gate_ptr[0], val(nleaf - 1)));
+            if (f.tail) { RFLU_HIP(hipStreamWaitEvent(P, f.tail, 0)); f.tail = nullptr; }
+        }
         // the initial state travels on the caller's stream, in front of everything the engine is going to wait for
         RFLU_HIP(hipMemcpyAsync(reinterpret_cast<char*>(est) + skip, reinterpret_cast<char*>(img) + skip, bytes - skip, hipMemcpyHostToDevice, P));
         RFLU_TRY(record_on(P, EX + (size_t)nblk + 1));
@@ -1049,7 +1056,12 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         a.st = est; a.leaf_gate = h->gate_ptr[0]; a.gate_base = gbase; a.info = h->info_dev; a.gemm_flags = h->tune.gemm_flags;
         a.arrived = h->eng_host_mode ? &est->arrived : nullptr;
         a.rows_final = h->eng_host_mode ? h->eng_rows_final_dev : nullptr;
-        for (int i = 0; i < 8; ++i) a.x[i] = h->tune.engine_x[i];
+        a.write_through = h->tune.engine_write_through != 0;
+        a.leaf_xcds = h->tune.engine_leaf_xcds;
+        a.leaf_wgs = h->tune.engine_leaf_wgs;
+        // host entry: whole-block-column operations that lag the chain by this many block columns go first (engine.hip), so that
+        // block rows become final -- and leave -- while the factorization runs
+        a.host_lag = h->eng_host_mode ? h->tune.engine_host_lag : 0;
         // Engine to the end: from the first panel of at most `local_rows` rows on the chain wants its XCD-local leaves back (worth 1.2 ms at
         // N=16384), and the engine has little left to do: its workgroups on the chain's XCD retire two leaves earlier, the first such
         // leaf waits until they are gone (RFLU_ENGINE_RETIRE=0: they stay, every leaf any-placement)
@@ -1062,7 +1074,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
             // more than the faster leaves for longer: N=16384 75.2-76.5 ms at 4096 / 74.4-75.2 at 2048, N=12288 44.8 / 47.1, N=8192 25.8 / 27.7)
             const int64_t retire_rows = h->tune.engine_retire >= 0 ? h->tune.engine_retire : (m >= 16384 ? 2048 : 4096);
             const int64_t local_rows = std::min<int64_t>(local_max, retire_rows);
-            if (retire_rows > 0 && eng_end >= nblk && !h->eng_host_mode && f.pivot && h->panel_local == 2 && !h->coop_launch && local_rows >= 1024 && m > local_rows + 4 * NB) {
+            if (retire_rows > 0 && eng_end >= nblk && !h->eng_host_mode && !h->tune.engine_replay && f.pivot && h->panel_local == 2 && !h->coop_launch && local_rows >= 1024 && m > local_rows + 4 * NB) {
                 eng_retire_leaf = (m - local_rows + NB - 1) / NB;   // first leaf whose panel has at most local_rows rows
                 a.retire_xcc = h->panel_xcc;
                 a.retire_leaf = (int)std::max<int64_t>(1, eng_retire_leaf - 2);
@@ -1071,9 +1083,9 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         a.trace = nullptr;
         long long*& eng_trace_buf = h->eng_trace_buf;   // measurement only (RFLU_ENGINE_TRACE=1): stamps of the leaf windows, printed at the next call
         if (env_str("RFLU_ENGINE_TRACE")) {
-            if (!eng_trace_buf) RFLU_HIP(hipMalloc((void**)&eng_trace_buf, (4096 * 4 + 8) * sizeof(long long)));
+            if (!eng_trace_buf) RFLU_HIP(hipMalloc((void**)&eng_trace_buf, (4096 * 4 + 16) * sizeof(long long)));
             else {
-                std::vector<long long> hs(4096 * 4 + 8);
+                std::vector<long long> hs(4096 * 4 + 16);
                 RFLU_HIP(hipMemcpy(hs.data(), eng_trace_buf, hs.size() * sizeof(long long), hipMemcpyDeviceToHost));
                 double s01 = 0, s12 = 0, s23 = 0, sq = 0; int cnt = 0;
                 for (int g = 1; g + 1 < (int)nleaf && g < 4095; ++g) {
@@ -1089,30 +1101,52 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                         fprintf(stderr, "[rflu] engine workgroup time (previous call, %.1f workgroup-ms): block-column tiles %.1f %%, leaf-window tiles %.1f %%, strips + solves %.1f %%, deferred interchanges %.1f %%, between units %.1f %% (of which asleep with nothing eligible %.1f %%, count + publication behind a unit %.1f %%, scan / claim / acquire %.1f %%)\n",
                                 tot / 1e5, 100.0 * ac[0] / tot, 100.0 * ac[1] / tot, 100.0 * ac[2] / tot, 100.0 * ac[3] / tot, 100.0 * ac[4] / tot, 100.0 * ac[5] / tot, 100.0 * ac[6] / tot, 100.0 * (ac[4] - ac[5] - ac[6]) / tot);
                 }
-                for (int g = 40; g < 44 && g + 1 < (int)nleaf; ++g)
-                    fprintf(stderr, "   leaf %d: %.1f %.1f %.1f | since previous window complete %.1f\n", g, (hs[g * 4 + 1] - hs[g * 4]) / 100.0, (hs[g * 4 + 2] - hs[g * 4 + 1]) / 100.0, (hs[g * 4 + 3] - hs[g * 4 + 2]) / 100.0, (hs[g * 4] - hs[(g - 1) * 4 + 3]) / 100.0);
+                // leaf by leaf (RFLU_ENGINE_TRACE=first:count): when LEAF(g) was first claimed on the column block of its first columns (ms since LEAF(0)'s first
+                // claim), its three phases, and how long that column block had been idle before (the engine waiting for the chain) -- for the LAST
+                // leaf but one of a block column that column block is the NEXT block column's: the window the chain's last leaf waits for
+                int tg0 = 40, tgn = 4;
+                if (const char* e = env_str("RFLU_ENGINE_TRACE")) { if (strchr(e, ':')) sscanf(e, "%d:%d", &tg0, &tgn); }
+                for (int g = std::max(tg0, 1); g < tg0 + tgn && g + 1 < (int)nleaf && g < 4095; ++g)
+                {
+                    fprintf(stderr, "   leaf %d: first claim at %.3f ms | stage 0 %.1f us | to first tile %.1f | tiles %.1f | idle before %.1f", g, (hs[g * 4] - hs[0]) / 1e5,
+                            (hs[g * 4 + 1] - hs[g * 4]) / 100.0, (hs[g * 4 + 2] - hs[g * 4 + 1]) / 100.0, (hs[g * 4 + 3] - hs[g * 4 + 2]) / 100.0, (hs[g * 4] - hs[(g - 1) * 4 + 3]) / 100.0);
+                    const long long* n4 = hs.data() + (size_t)(2048 + g) * 4;   // the same leaf on the next block column's first column block
+                    if (g < 2048 && n4[0] && n4[3])
+                        fprintf(stderr, " || next block column: first claim at %.3f ms (%.1f us after the previous leaf's window there was complete) | stage 0 %.1f | to first tile %.1f | tiles %.1f",
+                                (n4[0] - hs[0]) / 1e5, (n4[0] - n4[-1]) / 100.0, (n4[1] - n4[0]) / 100.0, (n4[2] - n4[1]) / 100.0, (n4[3] - n4[2]) / 100.0);
+                    fprintf(stderr, "\n");
+                }
             }
-            RFLU_HIP(hipMemsetAsync(eng_trace_buf, 0, (4096 * 4 + 8) * sizeof(long long), P));
+            RFLU_HIP(hipMemsetAsync(eng_trace_buf, 0, (4096 * 4 + 16) * sizeof(long long), P));
             a.trace = eng_trace_buf;
         }
-        // host entry: whole-block-column operations that lag the chain by this many block columns go first (engine.hip), so that
-        // block rows become final -- and leave -- while the factorization runs (N=16384: 3: 123 ms, 5: 109-110, 8: 112, none: 118)
-        if (h->eng_host_mode && a.x[3] == 0) a.x[3] = 5;
         const int wgs = h->tune.engine_wgs > 0 ? h->tune.engine_wgs : 2 * (h->num_cus - 32);
         if (img->remaining > 0) {
             // measurement (rflu_profile_enable(2)): the engine kernel as ONE launch of the class the bulk GEMM reports under -- its flops are
             // the Schur updates it performs (every operation's 2 M N K), its duration the whole residency, waiting included
-            double eng_flops = 0;
-            for (int cb = 0; cb < geo.ncb; ++cb)
+            // ... and its algorithmic bytes: per operation the panel pieces once (A: M x K, B: K x N), the Schur block in and out (2 M N), the
+            // solved block row in and out (2 K N), and the interchanges (two rows read + written per pivot and column: 4 per entry), the
+            // deferred ones on the finished columns to the left included
+            double eng_flops = 0, eng_bytes = 0;
+            for (int cb = 0; cb < geo.ncb; ++cb) {
                 for (int k = 0; k < eng_nops(geo, cb); ++k) {
                     const EngOp o = eng_op(geo, cb, k);
-                    eng_flops += 2.0 * (double)(geo.m - (o.j0 + o.jb)) * (double)o.nc * (double)o.jb;
+                    if (o.nc <= 0) continue;
+                    const double M = (double)std::max(geo.m - (o.j0 + o.jb), 0), N = (double)o.nc, K = (double)o.jb;
+                    eng_flops += 2.0 * M * N * K;
+                    eng_bytes += sizeof(T) * (M * K + K * N + 2.0 * M * N + 2.0 * K * N + 0.5 * K * K + (f.pivot ? 4.0 * K * N : 0.0));
                 }
+                if (f.pivot && eng_pb(geo, cb) < geo.nbp) {   // left op 0 (on average half of the block column's pivots per strip) + the later block columns as a whole
+                    const double nc = (double)(std::min<int64_t>(n, (int64_t)(cb + 1) * geo.Wc) - (int64_t)cb * geo.Wc);
+                    const double later = (double)std::max<int64_t>(std::min<int64_t>((int64_t)geo.nbp * W, mn) - (int64_t)(eng_pb(geo, cb) + 1) * W, 0);
+                    eng_bytes += sizeof(T) * 4.0 * nc * (0.5 * (double)std::min<int64_t>(W, mn - (int64_t)eng_pb(geo, cb) * W) + later);
+                }
+            }
             hipStream_t saved = h->stream;
             h->stream = E;
             int rc;
             {
-                ProfScope ps(h, RFLU_K_GEMM, eng_flops, sizeof(T) * (double)m * (double)n);
+                ProfScope ps(h, RFLU_K_GEMM, eng_flops, eng_bytes);
                 rc = launch_engine<T>(h, E, a, wgs);
             }
             h->stream = saved;
@@ -1128,6 +1162,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
     }
     for (int64_t b = b_begin; b < nblk; ++b) {
         const bool in_eng = b < eng_end;
+        if (in_eng && h->tune.engine_replay) continue;   // (measurement: the engine alone)
         if (eng_end > 0 && b == eng_end) {   // the streams take over: the leaves are short enough for the XCD-local exchange again
             h->tune.panel_local_rows = restore_local.rows;
             restore_local.on = false;
@@ -1348,7 +1383,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
         // never see it start (the 2 s gate timeout turns that into RFLU_ERR_TIMEOUT).  A counter-collection run therefore asks
         // for RFLU_SCHEDULE=events: the lookahead schedule, whose cross-stream edges are hipEvents, to the end (same kernels on
         // the same shapes for the bulk of the work; scripts/collect_profiles.sh sets it for the --pmc passes only).
-        if (h->tune.schedule_events) leafwise = 0;
+        if (h->tune.schedule_events && !h->tune.engine_replay) leafwise = 0;
         {   // the leaf-wise / deep schedules hand work between streams through device-side gates: only with real CU-masked streams
             hipStream_t probe;
             RFLU_TRY(get_ustream(h, 32, &probe));
@@ -1392,7 +1427,7 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             // with pivoting (a Float32 pivot search may answer the engine's other summation order with another pivot sequence, NoPivot with
             // visibly other digits), the default block width of 512, i.e. more than 12288 columns (N=16384: 72 vs 75.5 ms; at 256-wide
             // block columns the streams win: N=12288 44.7 vs 43.7, N=8192 25.7 vs 24.0)
-            const bool eng_wanted = h->eng_host_mode || h->tune.engine == 1 ||
+            const bool eng_wanted = h->eng_host_mode || h->tune.engine == 1 || h->tune.engine_replay ||
                                     (h->tune.engine < 0 && sizeof(T) == 8 && pivot && default_bs && Wb == 512 && mn > 12288 && m >= n);
             if (eng_wanted && leafwise && Wb >= 2 * NB && Wb <= 512 && W_wide == 0 && m <= 32 * (int64_t)PANEL_THREADS && engine_usable<T>(h, f, Wb)) {
                 const int64_t er = h->eng_host_mode ? 0 : std::max<int64_t>(h->tune.engine_rows, 0);   // (host entry: every block column through the engine)
@@ -2119,6 +2154,21 @@ int rflu_debug_gate_stamps(rflu_handle_t handle, long long* out)
     CHECK_HANDLE(handle);
     if (!H(handle)->gate_stamps) { set_error("no gate trace (set RFLU_GATE_TRACE=1)"); return RFLU_ERR_ARG; }
     RFLU_HIP(hipMemcpy(out, H(handle)->gate_stamps, 3 * 4096 * sizeof(long long), hipMemcpyDeviceToHost));
+    return RFLU_OK;
+}
+
+int rflu_debug_engine_acct(rflu_handle_t handle, long long* out8)
+{
+    // RFLU_ENGINE_TRACE: the workgroup-time accumulators of the LAST engine launch on this handle (100 MHz ticks, summed over the
+    // workgroups): [0] block-column tiles, [1] leaf-window tiles, [2] strips + solves, [3] deferred interchanges, [4] between units,
+    // [5] (of 4) asleep, [6] (of 4) publications, [7] unused
+    if (!handle || !out8) return RFLU_ERR_ARG;
+    Handle* h = H(handle);
+    DeviceGuard device_guard__(h->device);
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!h->eng_trace_buf) return RFLU_OK;
+    RFLU_HIP(hipStreamSynchronize(h->stream));
+    RFLU_HIP(hipMemcpy(out8, h->eng_trace_buf + 4096 * 4, 8 * sizeof(long long), hipMemcpyDeviceToHost));   // (the finer split behind them: driver.cpp's own print)
     return RFLU_OK;
 }
 

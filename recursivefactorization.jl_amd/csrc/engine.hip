@@ -85,7 +85,7 @@ struct EngUnit {
     int64_t ld;
     EngGeo g;
     int gemm_flags;
-    int x2;
+    int write_through;
 };
 template <typename T>
 __device__ __forceinline__ EngUnit<T> eng_unit_args(const EngArgs<T>& a, T* smem)
@@ -100,7 +100,7 @@ __device__ __forceinline__ EngUnit<T> eng_unit_args(const EngArgs<T>& a, T* smem
     u.ld = a.ld;
     u.g = a.g;
     u.gemm_flags = a.gemm_flags;
-    u.x2 = a.x[2];
+    u.write_through = a.write_through;
     return u;
 }
 
@@ -236,7 +236,7 @@ __device__ __attribute__((noinline)) void eng_gemm_unit(const EngUnit<T> a, cons
     g.tiles_m = (g.M + G_BM - 1) / G_BM;
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
     g.vec_ok = (reinterpret_cast<uintptr_t>(Rg) % 16 == 0) && (a.ld % VW == 0) && (o.c_lo % VW == 0) && (o.j0 % VW == 0);
-    g.flags = a.gemm_flags | ((a.x2 & 1) ? 4 : 0);   // x[2] = 1: write-through C stores, no release fence behind a tile
+    g.flags = a.gemm_flags | (a.write_through ? 4 : 0);   // write-through C stores, no release fence behind a tile
     g.na_tiles_n = 0; g.sig_flag = nullptr; g.sig_val = 0; g.sig_cnt = nullptr;
     // G_GROUP_M tile rows are walked together, column after column: consecutive claims share the B panel, then the A panels
     int tile_m, tile_n;
@@ -312,24 +312,27 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
     const int tid = threadIdx.x, lane = tid & 63;
     int cb_lo = 0;             // column blocks in front of this one have nothing left for the main scan (monotone)
     int fin_b = 0;             // workgroup 0: block rows [0, fin_b) have been reported final (EngArgs::rows_final)
-    // x[4] = m > 0: workgroups with blockIdx % m == 1;  x[5] = k > 0: the workgroups of k XCDs (blockIdx % 8 in [1, k]);  x[6] = j > 0: of those, only blockIdx / 8 < j
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 7u;
     if (tid == 0) __hip_atomic_fetch_add(&st->xcc_wgs[my_xcc], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool may_retire = a.retire_leaf > 0 && (int)my_xcc == a.retire_xcc;
-    bool leaf_only = a.x[4] > 0 && (int)(blockIdx.x % (unsigned)a.x[4]) == 1;
-    if (a.x[5] > 0) leaf_only = (int)(blockIdx.x & 7) >= 1 && (int)(blockIdx.x & 7) <= a.x[5] && (a.x[6] <= 0 || (int)(blockIdx.x >> 3) < a.x[6]);
+    // The workgroups that serve the leaf windows only (K = 64: what the chain of leaves waits for finds a free workgroup at once instead of
+    // queueing behind 127-us tiles of the block-column updates): those with blockIdx % 8 in [1, leaf_xcds] and blockIdx / 8 < leaf_wgs --
+    // blockIdx % 8 is the XCD a workgroup of the first dispatch round lands on, so by default 16 workgroups of one XCD (N=16384: 97 -> 84 ms)
+    const bool leaf_only = a.leaf_xcds > 0 && (int)(blockIdx.x & 7) >= 1 && (int)(blockIdx.x & 7) <= a.leaf_xcds && (int)(blockIdx.x >> 3) < a.leaf_wgs;
 
     // every LEAF op of the block column pb is complete: on its own column blocks (they have nothing else left) and on those of the
-    // block column to its right
+    // `ahead` block columns to its right
     auto leaf_ops_complete = [&](int pb) -> bool {
         const int c0 = eng_first_cb(a.g, pb), n0 = eng_cbs_of_block(a.g, pb);
         for (int c = c0; c < c0 + n0; ++c)
             if ((unsigned)(eng_load(&st->cb[c].claim) >> 32) != ENG_SEQ_DONE) return false;
-        const int c1 = eng_first_cb(a.g, pb + 1), n1 = eng_cbs_of_block(a.g, pb + 1);
-        for (int c = c1; c < c1 + n1; ++c)
-            if ((int)eng_load(&st->cb[c].prog) < 2 * eng_leafn_end(a.g, c)) return false;
+        for (int q = pb + 1; q <= pb + eng_ahead(a.g); ++q) {
+            const int c1 = eng_first_cb(a.g, q), n1 = eng_cbs_of_block(a.g, q);
+            for (int c = c1; c < c1 + n1; ++c)
+                if ((int)eng_load(&st->cb[c].prog) < 2 * eng_ops_through_block(a.g, c, pb)) return false;
+        }
         return true;
     };
     auto left_op_ok = [&](int cb, int lk) -> bool {
@@ -376,6 +379,28 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     }
                 }
             }
+            // a ticket (the value a fetch-and-add on column block cb's claim word returned): this workgroup's unit if the unit exists
+            auto accept = [&](int cb, unsigned long long w) {
+                const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
+                if (seq == ENG_SEQ_DONE) return;
+                const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+                if ((int)u >= eng_units_of(o, (int)(seq & 1u), a.g.m)) return;   // (past the end: nobody's)
+                kind = ENG_MAIN; sel_cb = cb; sel_seq = seq; sel_unit = (int)u;
+                // The scan saw an eligible sequence; the add may have landed in a LATER one (published in between).  A later
+                // stage 1 is ready by construction; a later stage 0 needs its leaves -- practically never the case (a whole
+                // sequence would have to complete between this wave's scan and its add), but then the claim is held until
+                // they are there (bounded; the leaves do not depend on this workgroup)
+                if ((seq & 1u) == 0) {
+                    const long long t0 = wall_clock64();
+                    const bool wl = o.type == ENG_OP_BIG && eng_big_waits_for_left(a.g, (int)(seq >> 1));
+                    while ((leaves_done() < o.need ||
+                            (wl && (int)(eng_load(&st->cb[eng_first_cb(a.g, (int)(seq >> 1))].leftdone) >> 32) < eng_cbs_of_block(a.g, (int)(seq >> 1)))) &&
+                           eng_load(&st->abort) == 0) {
+                        __builtin_amdgcn_s_sleep(16);
+                        if (wall_clock64() - t0 > 400000000LL) break;   // (the idle timeout of the others raises the flag)
+                    }
+                }
+            };
             for (int attempt = 0; kind == ENG_NONE; ++attempt) {
                 // what this sweep is based on: if it finds nothing, the wave sleeps on these three words until one of them moves
                 const unsigned long long seen_epoch = eng_load(&st->epoch), seen_gate = eng_load(a.leaf_gate);
@@ -409,8 +434,6 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                             live = true;
                             const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
                             bool ok = o.need <= pd && (int)u < eng_units_of(o, (int)(seq & 1u), a.g.m) && min(a.g.n, (cb + 1) * a.g.Wc) <= have;
-                            // every x[4]-th workgroup serves the leaf-wise window only: the K = 64 operations the chain of leaves waits
-                            // for find a free workgroup at once instead of queueing behind 127-us tiles of the block-column updates
                             if (leaf_only && o.type == ENG_OP_BIG) ok = false;
                             // a block column as a whole is applied with ITS interchanges complete on all its columns (engine.hpp)
                             if (ok && o.type == ENG_OP_BIG && (seq & 1u) == 0 && eng_big_waits_for_left(a.g, (int)(seq >> 1)))
@@ -419,9 +442,9 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                                 key = a.policy ? (((o.j0 / NB) << 10) | cb) : ((1 << 24) | cb);
                                 // host entry: a block row can leave only when the panel has reached EVERY column block; with the
                                 // leftmost-first rule alone the far right is served last and the way back starts when the
-                                // factorization ends.  A whole-block-column operation that lags the chain by `lag` block columns
+                                // factorization ends.  A whole-block-column operation that lags the chain by `host_lag` block columns
                                 // or more goes first, oldest panel first.
-                                if (a.x[3] > 0 && o.type == ENG_OP_BIG && pd / (a.g.W / NB) - (int)(seq >> 1) >= a.x[3])
+                                if (a.host_lag > 0 && o.type == ENG_OP_BIG && pd / (a.g.W / NB) - (int)(seq >> 1) >= a.host_lag)
                                     key = ((int)(seq >> 1) << 10) | cb;
                             }
                         }
@@ -432,7 +455,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
                     best = min(best, mk);
-                    if (a.policy == 0 && a.x[3] <= 0 && best != INT_MAX) break;   // leftmost first: nothing further right can beat it
+                    if (a.policy == 0 && a.host_lag <= 0 && best != INT_MAX) break;   // leftmost first: nothing further right can beat it
                 }
                 if (first_live != INT_MAX) cb_lo = first_live;
                 if (best != INT_MAX) {
@@ -443,47 +466,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     unsigned long long w = 0;
                     if (lane == 0) w = __hip_atomic_fetch_add(&st->cb[cb].claim, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     w = __shfl(w, 0);
-                    const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
-                    if (seq != ENG_SEQ_DONE) {
-                        const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
-                        if ((int)u < eng_units_of(o, (int)(seq & 1u), a.g.m)) {
-                            kind = ENG_MAIN; sel_cb = cb; sel_seq = seq; sel_unit = (int)u;
-                            // Which tile of a whole-block-column update: the one the ticket names, or (x[7]) the next one of this XCD's band
-                            // of tile rows -- whoever comes first takes tiles in order, so the workgroups of one XCD would otherwise work on
-                            // tiles spread over the whole column block and every L2 would stream every operand panel of it
-                            if (a.x[7] > 0 && (seq & 1u) != 0 && o.type == ENG_OP_BIG) {
-                                const int tiles_m = (a.g.m - (o.j0 + o.jb) + G_BM - 1) / G_BM, tiles_n = (o.nc + G_BN - 1) / G_BN;
-                                const int units = tiles_m * tiles_n, per_group = G_GROUP_M * tiles_n, ngroups = (tiles_m + G_GROUP_M - 1) / G_GROUP_M;
-                                unsigned xcc;
-                                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                                int picked = -1;
-                                for (int k = 0; k < 8 && picked < 0; ++k) {
-                                    const int r = (int)((xcc + (unsigned)k) & 7u);
-                                    const int s0 = (r * ngroups / 8) * per_group, s1 = min(((r + 1) * ngroups / 8) * per_group, units);
-                                    if (s1 <= s0) continue;
-                                    unsigned long long i = 0;
-                                    if (lane == 0) i = __hip_atomic_fetch_add(&st->cb[cb].xclaim[r], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    i = __shfl(i, 0);
-                                    if (s0 + (int)i < s1) picked = s0 + (int)i;
-                                }
-                                if (picked >= 0) sel_unit = picked;   // (every ticket finds a tile: as many tiles as tickets)
-                            }
-                            // The scan saw an eligible sequence; the add may have landed in a LATER one (published in between).  A later
-                            // stage 1 is ready by construction; a later stage 0 needs its leaves -- practically never the case (a whole
-                            // sequence would have to complete between this wave's scan and its add), but then the claim is held until
-                            // they are there (bounded; the leaves do not depend on this workgroup)
-                            if ((seq & 1u) == 0) {
-                                const long long t0 = wall_clock64();
-                                const bool wl = o.type == ENG_OP_BIG && eng_big_waits_for_left(a.g, (int)(seq >> 1));
-                                while ((leaves_done() < o.need ||
-                                        (wl && (int)(eng_load(&st->cb[eng_first_cb(a.g, (int)(seq >> 1))].leftdone) >> 32) < eng_cbs_of_block(a.g, (int)(seq >> 1)))) &&
-                                       eng_load(&st->abort) == 0) {
-                                    __builtin_amdgcn_s_sleep(16);
-                                    if (wall_clock64() - t0 > 400000000LL) break;   // (the idle timeout of the others raises the flag)
-                                }
-                            }
-                        }
-                    }
+                    accept(cb, w);
                     continue;   // (past the end: look again)
                 }
                 // ---- deferred interchanges on the finished column blocks ---------------------------------------------------
@@ -556,7 +539,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 // stage was published, and the tiles other workgroups write during it are not read by this one -- the second and later
                 // tiles of the same stage keep their L1 (the U12 strip they share) and save the fence
                 const bool same_stage = kind == ENG_MAIN && (sel_seq & 1u) != 0 && sel_cb == last_cb && sel_seq == last_seq;
-                if ((kind == ENG_MAIN || kind == ENG_LEFT) && !(a.x[1] & 1) && !same_stage) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if ((kind == ENG_MAIN || kind == ENG_LEFT) && !same_stage) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 s_sel[0] = kind; s_sel[1] = sel_cb; s_sel[2] = (int)sel_seq; s_sel[3] = sel_unit;
             }
             // (all lanes of the wave: the values are wave-uniform)
@@ -573,6 +556,9 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
             acct_k = (seq & 1u) == 0 ? 2 : (o.type == ENG_OP_BIG ? 0 : 1);
             if (a.trace && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == (o.j0 + o.jb + NB) / a.g.Wc)
                 a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 2 : 0)] = wall_clock64();
+            // (second set, leaves < 2048: the same leaf on the first column block of the NEXT block column)
+            if (a.trace && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == eng_first_cb(a.g, o.j0 / a.g.W + 1) && o.j0 / NB < 2048)
+                a.trace[(2048 + o.j0 / NB) * 4 + ((seq & 1u) ? 2 : 0)] = wall_clock64();
             if ((seq & 1u) == 0) eng_prep_unit<T>(ua, o, unit);
             else eng_gemm_unit<T>(ua, o, unit);
         } else {
@@ -584,7 +570,7 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         __syncthreads();
         if (tid == 0) {
             // a Schur tile stored write-through has nothing left in this XCD's L2 (its stores are acknowledged: s_waitcnt above)
-            if (!(a.x[0] & 1) && !((a.x[2] & 1) && kind == ENG_MAIN && (seq & 1u) != 0)) eng_release();
+            if (!(a.write_through && kind == ENG_MAIN && (seq & 1u) != 0)) eng_release();
             EngCB* c = &st->cb[cb];
             if (kind == ENG_MAIN) {
                 const int units = eng_units(a, cb, seq);
@@ -605,10 +591,10 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 if ((int)d == units) {
                     if (a.trace && o.type == ENG_OP_LEAF && cb == (o.j0 + o.jb + NB) / a.g.Wc)
                         a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
+                    if (a.trace && o.type == ENG_OP_LEAF && cb == eng_first_cb(a.g, o.j0 / a.g.W + 1) && o.j0 / NB < 2048)
+                        a.trace[(2048 + o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                     eng_store(&c->done, 0ull);
-                    if (a.x[7] > 0 && (seq & 1u) != 0 && o.type == ENG_OP_BIG)
-                        for (int r = 0; r < 8; ++r) eng_store(&c->xclaim[r], 0ull);
                     const unsigned end = 2u * (unsigned)eng_nops(a.g, cb);
                     unsigned ns = seq + 1;
                     while (ns < end && eng_units(a, cb, ns) == 0) ++ns;   // (an operation with no columns left, a panel with no rows below it)

@@ -30,8 +30,6 @@ struct EngCB {
     unsigned long long leftdone; // (first column block of a block column) own << 32 | left, see "order between the interchanges ..." below
     unsigned long long lprog;    // left operations completed (lprog >= 1: the block column's own later interchanges have reached this column block)
     unsigned long long bigdone;  // (first column block of a block column) column blocks that have completed BIG(this block column)
-    unsigned long long xclaim[8]; // tiles of the current whole-block-column update handed out per band of tile rows: the workgroups of XCD x start with
-                                 // band x (engine.hip: a ticket from `claim` says THAT a tile is due, these say WHICH), zeroed by whoever publishes the next sequence
 };
 
 struct EngState {
@@ -56,6 +54,12 @@ struct EngGeo {
     int nbp;        // the engine serves the leaves of block columns [0, nbp)
     int ncb;        // column blocks of width Wc covering [0, n)
     int pivot;
+    int ahead;      // a leaf is applied leaf by leaf (K = 64) to its own block column and to the `ahead` block columns right of it (>= 1); a block
+                    // column as a whole (K = W) to everything further right.  1 is the leaf-wise stream schedule's window.  With 1 the block column
+                    // right of the panel receives BIG(b - 1) only once block column b - 1 is complete, and then has to catch up, one leaf window
+                    // after the other (each two dependent stages), with the leaves of block column b factored meanwhile -- the chain stood at the
+                    // LAST leaf of every block column for 0.4 .. 2.5 ms (N=16384: all of its 12 ms of waiting, profiles/r06*_leaves.txt); with 2
+                    // that column block has everything but the current block column's leaves a whole block column earlier
 };
 
 enum { ENG_OP_BIG = 0, ENG_OP_LEAF = 1 };
@@ -87,20 +91,29 @@ RFLU_HD int eng_cbs_of_block(const EngGeo& g, int b)                            
 }
 
 // operations of column block cb (in block column pb), in order:
-//   BIG(b),  b = 0 .. min(pb - 1, nbp) - 1 : block column b as a whole (K = W) -- block columns at least two to the left
-//   LEAF(g), g = leaves of block column pb - 1 (if that one is served): K = 64, the leaf-wise schedule's "next block column" window
+//   BIG(b),  b = 0 .. min(pb - ahead, nbp) - 1 : block column b as a whole (K = W) -- block columns more than `ahead` to the left
+//   LEAF(g), g = leaves of block columns pb - ahead .. pb - 1 (those that are served): K = 64, the leaf windows of the block columns in front
 //   LEAF(g), g = leaves of block column pb itself but its last (if served): K = 64 on the columns right of the leaf's lookahead strip
+RFLU_HD int eng_ahead(const EngGeo& g) { return g.ahead >= 1 ? g.ahead : 1; }
 RFLU_HD int eng_nbig(const EngGeo& g, int cb)
 {
-    int v = eng_pb(g, cb) - 1;
+    int v = eng_pb(g, cb) - eng_ahead(g);
     if (v < 0) v = 0;
     return v < g.nbp ? v : g.nbp;
 }
-RFLU_HD int eng_nleafn(const EngGeo& g, int cb)
+// LEAF ops of cb that belong to the block columns in front of its own, up to (not including) block column `upto` (<= pb)
+RFLU_HD int eng_nleaf_front(const EngGeo& g, int cb, int upto)
 {
     const int pb = eng_pb(g, cb);
-    return (pb >= 1 && pb - 1 < g.nbp) ? eng_leaves_of_block(g, pb - 1) : 0;
+    int lo = pb - eng_ahead(g);
+    if (lo < 0) lo = 0;
+    int hi = upto < pb ? upto : pb;
+    if (hi > g.nbp) hi = g.nbp;
+    int cnt = 0;
+    for (int b = lo; b < hi; ++b) cnt += eng_leaves_of_block(g, b);
+    return cnt;
 }
+RFLU_HD int eng_nleafn(const EngGeo& g, int cb) { return eng_nleaf_front(g, cb, eng_pb(g, cb)); }
 RFLU_HD int eng_nleafo(const EngGeo& g, int cb)
 {
     const int pb = eng_pb(g, cb);
@@ -131,8 +144,11 @@ RFLU_HD EngOp eng_op(const EngGeo& g, int cb, int k)
     }
     const int nln = eng_nleafn(g, cb);
     int leaf;
-    if (k - nbig < nln) leaf = (pb - 1) * LPB + (k - nbig);
-    else leaf = pb * LPB + (k - nbig - nln);
+    if (k - nbig < nln) {   // the block columns in front are full ones (only the last block column of a matrix can be short, and it has nothing behind it)
+        int lo = pb - eng_ahead(g);
+        if (lo < 0) lo = 0;
+        leaf = lo * LPB + (k - nbig);
+    } else leaf = pb * LPB + (k - nbig - nln);
     o.type = ENG_OP_LEAF;
     o.j0 = leaf * NB;
     o.jb = g.mn - o.j0 < NB ? g.mn - o.j0 : NB;
@@ -150,7 +166,7 @@ RFLU_HD int eng_leaf_op_index(const EngGeo& g, int cb, int leaf)
 {
     const int LPB = g.W / NB;
     const int lb = leaf / LPB;
-    if (lb == eng_pb(g, cb) - 1) return eng_nbig(g, cb) + (leaf - lb * LPB);
+    if (lb < eng_pb(g, cb)) return eng_nbig(g, cb) + eng_nleaf_front(g, cb, lb) + (leaf - lb * LPB);
     return eng_nbig(g, cb) + eng_nleafn(g, cb) + (leaf - lb * LPB);
 }
 
@@ -204,10 +220,11 @@ RFLU_HD int eng_units_of(const EngOp& o, int stage, int m)
 RFLU_HD bool eng_big_waits_for_left(const EngGeo& g, int b) { return g.pivot && eng_leaves_of_block(g, b) > 1; }
 RFLU_HD int eng_big_users(const EngGeo& g, int b)
 {
-    const int v = g.ncb - eng_first_cb(g, b + 2);
+    const int v = g.ncb - eng_first_cb(g, b + eng_ahead(g) + 1);
     return (b < g.nbp && v > 0) ? v : 0;
 }
-RFLU_HD int eng_leafn_end(const EngGeo& g, int cb) { return eng_nbig(g, cb) + eng_nleafn(g, cb); }   // ops of cb up to its LEAF ops of the block column in front
+// ops of cb up to and including its LEAF ops of block column b (a block column in front of cb's own)
+RFLU_HD int eng_ops_through_block(const EngGeo& g, int cb, int b) { return eng_nbig(g, cb) + eng_nleaf_front(g, cb, b + 1); }
 
 template <typename T>
 struct EngArgs {
@@ -229,7 +246,11 @@ struct EngArgs {
     unsigned long long* rows_final;        // host-visible word: rows [0, *rows_final) of the factors are final (nullptr: nobody asks)
     int gemm_flags;
     long long* trace;   // measurement (RFLU_ENGINE_TRACE): per leaf g four wall-clock stamps of LEAF(g) on the column block of its first columns
-    int x[8];       // experiment switches (Tune::engine_x)
+    // (named defaults, Tune: RFLU_ENGINE_WRITE_THROUGH / _LEAF_XCDS / _LEAF_WGS / _HOST_LAG)
+    int write_through;   // Schur tiles stored write-through (sc1): no agent-scope release -- an L2 write-back -- behind a tile
+    int leaf_xcds;       // the workgroups with blockIdx % 8 in [1, leaf_xcds] and blockIdx / 8 < leaf_wgs serve the leaf windows (K = 64) only
+    int leaf_wgs;
+    int host_lag;        // host entry: whole-block-column operations that lag the chain by this many block columns go first (0: never)
     int retire_xcc; // the workgroups on this XCC leave once retire_leaf leaves are done (-1: nobody retires): the short panels at the end, which
     int retire_leaf; // the engine has little to do for, get the XCD their XCD-local exchange needs (driver.cpp: factor_leafwise)
 };

@@ -122,9 +122,17 @@ struct Tune {
     int engine_wc = 512;               // RFLU_ENGINE_WC: width of the engine's column blocks (a multiple of 128 dividing the block-column width; N=16384: 128: 82.7 ms, 256: 80.5, 512: 79.6)
     int engine_retire = -1;            // RFLU_ENGINE_RETIRE: from the first panel of at most this many rows on the engine's workgroups on the chain's XCD are gone and the
                                        // leaves XCD-local (-1: 4096, 2048 for matrices of 16384 rows or more; 0: they stay to the end, every leaf any-placement)
+    int engine_replay = 0;             // RFLU_ENGINE_REPLAY=1 (measurement): the engine ALONE on the image a previous factorization of the same shape left behind -- every
+                                       // leaf counts as done from the start, no chain is launched (results are meaningless; this is what rocprofv3 --pmc, which runs
+                                       // one kernel at a time, can collect the resident kernel's counters on: scripts/pmc_engine.sh)
     int engine_host = 1;               // RFLU_ENGINE_HOST: host-pointer entry (rflu_getrf_*) through the engine: the way in overlaps the factorization
-    int engine_x[8] = {0, 0, 1, 0, 0, 1, 16, 0};   // RFLU_ENGINE_X0..7 (engine.hip): X2 = 1: Schur tiles stored write-through (no L2 write-back per tile), X3: lag bound of the
-                                       // host entry, X4 / X5 / X6: which workgroups serve the leaf windows only (default: 16 of XCD 1); X0 = 1 / X1 = 1: no release / acquire (timing only)
+    int engine_write_through = 1;      // RFLU_ENGINE_WRITE_THROUGH: Schur tiles stored write-through, no L2 write-back per tile (N=16384: 84 -> 79 ms; 0: release fence per tile)
+    int engine_leaf_xcds = 1;          // RFLU_ENGINE_LEAF_XCDS / RFLU_ENGINE_LEAF_WGS: the workgroups with blockIdx % 8 in [1, xcds] and blockIdx / 8 < wgs serve the
+    int engine_leaf_wgs = 16;          //   leaf windows (K = 64) only: what the chain waits for never queues behind 127-us tiles (N=16384: 97 -> 84 ms; xcds 0: none)
+    int engine_ahead = 1;              // RFLU_ENGINE_AHEAD: a leaf is applied leaf by leaf (K = 64) to its own block column and to this many block columns right of it
+                                       // (engine.hpp: EngGeo::ahead; 1 = the stream schedule's window: the chain then waits 0.4 .. 2.5 ms at the last leaf of every block column)
+    int engine_host_lag = 5;           // RFLU_ENGINE_HOST_LAG: host entry: whole-block-column operations that lag the chain by this many block columns go first, so
+                                       // that block rows become final -- and leave -- while the factorization runs (N=16384: 3: 123 ms, 5: 109-110, 8: 112, 0 = never: 118)
     void load_env();                   // driver.cpp
 };
 

@@ -40,4 +40,10 @@ for i in range(0, len(leaves), lpb):
     print("  %3d: %d | %6.1f | %6.1f | %5.1f | %5.1f | %6.1f | %5.1f | %.2f" % (i // lpb, len(blk), av[0], av[1], av[2], av[3], per, gaps, per * len(blk) / 1e3))
     for k in range(4): tot[k] += av[k] * len(blk)
     tot[4] += per * len(blk); tot[5] += gaps * len(blk)
+if len(sys.argv) > 4:   # per-leaf rows for leaves [a, b)
+    a_, b_ = (int(x) for x in sys.argv[4].split(":"))
+    print("leaf: start ms | leaf us | lookahead launch us | K=64 update us | period us")
+    for g in range(a_, min(b_, len(leaves))):
+        nxt = leaves[g + 1][0] if g + 1 < len(leaves) else t1
+        print("  %3d: %7.3f | %6.1f | %6.1f | %5.1f | %6.1f" % (g, (leaves[g][0] - t0) / 1e6, leaves[g][1], leaves[g][2], leaves[g][3], (nxt - leaves[g][0]) / 1e3))
 print("sums (ms): leaf %.2f, lookahead launch %.2f, K=64 update %.2f, other %.2f, periods %.2f, gaps %.2f" % tuple(x / 1e3 for x in tot))

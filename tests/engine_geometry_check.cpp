@@ -22,10 +22,30 @@ int main(int argc, char** argv)
                 const int nblk = (g.mn + W - 1) / W;
                 g.ncb = (n + Wc - 1) / Wc;
                 if (g.ncb > ENG_MAX_CB) continue;
+                for (int ahead : {1, 2, 3})
                 for (int nbp : {nblk, nblk > 2 ? nblk / 2 : nblk}) {
                     g.nbp = nbp;
+                    g.ahead = ahead;   // leaf windows over the own block column and `ahead` block columns right of it (engine.hpp)
                     ++cases;
                     const int served_leaves = (std::min(nbp * W, g.mn) + NB - 1) / NB;
+                    // the per-block-column counts the interchange ordering rests on (engine.hpp: "order between the interchanges ..."): who has
+                    // BIG(b), and where the LEAF ops of block column b end in the lists of the column blocks in front of which it lies
+                    for (int b = 0; b < nbp; ++b) {
+                        int users = 0;
+                        for (int cb = 0; cb < g.ncb; ++cb) users += eng_nbig(g, cb) > b;
+                        if (users != eng_big_users(g, b)) { if (bad++ < 10) printf("big users W=%d Wc=%d m=%d n=%d ahead=%d b=%d: %d vs %d\n", W, Wc, m, n, ahead, b, users, eng_big_users(g, b)); }
+                        for (int cb = 0; cb < g.ncb; ++cb) {
+                            const int pb = eng_pb(g, cb);
+                            int last = -1;   // last op of cb that applies a leaf of block column b leaf by leaf
+                            for (int k = 0; k < eng_nops(g, cb); ++k) {
+                                const EngOp o = eng_op(g, cb, k);
+                                if (o.type == ENG_OP_LEAF && o.j0 / W == b) last = k;
+                            }
+                            if (pb > b && pb <= b + ahead) {
+                                if (eng_ops_through_block(g, cb, b) != last + 1 && !(last < 0 && eng_leaves_of_block(g, b) == 0)) { if (bad++ < 10) printf("ops through block W=%d Wc=%d m=%d n=%d ahead=%d b=%d cb=%d: %d vs %d\n", W, Wc, m, n, ahead, b, cb, eng_ops_through_block(g, cb, b), last + 1); }
+                            } else if (pb != b && last >= 0) { if (bad++ < 10) printf("leaf op outside the window W=%d Wc=%d m=%d n=%d ahead=%d b=%d cb=%d\n", W, Wc, m, n, ahead, b, cb); }
+                        }
+                    }
                     for (int cb = 0; cb < g.ncb; ++cb) {
                         const int c_first = cb * Wc, c_last = std::min(n, c_first + Wc);
                         std::vector<std::vector<int>> got(c_last - c_first);

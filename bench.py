@@ -396,6 +396,7 @@ def main():
         barrier()
         ks = h.profile()
         h.profile_enable(False)
+        through_engine = h.last_path() == 4   # RFLU_PATH_HIP_ENGINE: the trailing updates ran inside the resident engine_kernel
         g2, lw_small, lw_wide = ks["gemm"], ks["laswp"], ks["laswp_wide"]
         lw = {k: lw_small[k] + lw_wide[k] for k in ("ms", "launches", "work")}
         if roof is not None and g2["launches"] > 0 and g2["ms"] > 0:
@@ -418,22 +419,38 @@ def main():
                                         "(block-column lookahead, then leaf-wise): the bulk updates on the CU-masked stream "
                                         "(224 of 256 CUs) next to the critical path, with the clock the power management grants "
                                         "after the light phases (DESIGN.md section 7); sum of flops / sum of launch durations")
-            if g2["launches"] <= 2:
+            if through_engine:
                 # the shipped schedule of this size runs its updates in ONE resident kernel (csrc/engine.hip: the persistent update engine,
-                # default for Float64 pivoted matrices of more than 12288 columns): that launch is the dominant kernel
+                # default for pivoted matrices of more than 12288 columns): that launch is the dominant kernel
                 roof["kernel"] = ("engine_kernel (persistent update engine: interchanges, block-row solves and every Schur tile "
                                   "C -= A*B of the factorization, pulled from per-column-block counters; the tile code is gemm_sub_kernel's)")
                 roof["note_in_schedule"] = ("ONE launch: the engine is resident on 224 of 256 CUs for the whole factorization.  flops = the "
                                             "Schur updates it performs (sum of 2 M N K over its operations), duration = its residency (HIP "
                                             "event pair on its stream), i.e. waiting for the chain of leaves included -- RFLU_ENGINE_TRACE=1 "
-                                            "splits the workgroups' time (DESIGN.md section 3.12: tiles 59 + 8 %, strips and solves 6 %, "
-                                            "between units 26 %); the tile kernel by itself is frac_profiled")
-                # HBM traffic: the PMC figure under profiles/ belongs to the bulk tile kernel of the profiled pass (per gemm_sub_kernel launch);
-                # counter collection runs one kernel at a time, which a resident kernel that waits for the chain's kernels cannot survive
+                                            "splits the workgroups' time (profiles/: *_engine_workgroup_time.txt; DESIGN.md section 3: tiles 58 + 8 %, "
+                                            "strips and solves 6 %, between units 27 %); the tile kernel by itself is frac_profiled")
+                # HBM traffic of the resident kernel: rocprofv3 --pmc runs one kernel at a time, which a kernel that waits for the chain's
+                # kernels cannot survive -- the counters are those of the engine REPLAYED ALONE on a factored image (RFLU_ENGINE_REPLAY=1:
+                # the same operations on the same addresses with every leaf counted as done, scripts/pmc_engine.sh), committed under
+                # profiles/ with the hash of the sources they were measured on
                 roof["traffic_profiled"] = roof.get("traffic")
                 roof["traffic"] = None
-                roof["note"] = (roof["note_in_schedule"] + "; traffic: null for the resident kernel (rocprofv3 --pmc serialises kernels; "
-                                "traffic_profiled = HBM bytes per launch of the tile kernel in the profiled pass); " + roof["note"])
+                etraffic_note = ("traffic: null -- no replayed-engine PMC pass of THIS build under profiles/ (scripts/pmc_engine.sh, "
+                                 "scripts/make_engine_traffic.py)")
+                try:
+                    with open(os.path.join(ROOT, "profiles", "engine_traffic.json")) as f:
+                        ej = json.load(f)
+                    if ej.get("n") == n and ej.get("dtype") == sfx and ej.get("sources_sha1") == bmod.sources_digest():
+                        roof["traffic"] = ej["hbm_bytes_per_launch"]
+                        roof["traffic_ratio"] = round(ej["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 3)
+                        roof["mfma_busy_frac_replayed"] = ej.get("mfma_busy_frac")
+                        roof["replayed_alone_tflops"] = ej.get("replay_alone_tflops")
+                        etraffic_note = ("traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 of the ONE engine_kernel launch replayed alone (separate rocprofv3 "
+                                         "--pmc passes of this build): " + ej.get("source", "profiles/"))
+                except (OSError, ValueError, KeyError, NameError):
+                    pass
+                roof["note"] = (roof["note_in_schedule"] + "; " + etraffic_note + "; traffic_profiled = HBM bytes per launch of the tile "
+                                "kernel in the profiled single-stream pass; " + roof["note"])
         if lw["launches"] > 0 and lw["ms"] > 0:
             tbs = lw["work"] / (lw["ms"] * 1e-3) / 1e12
             esz = 8 if sfx == "f64" else 4
@@ -471,6 +488,47 @@ def main():
                 laswp["alone"] = {"achieved": round(ta * 1e3, 1), "frac": round(ta / 8.0, 4), "launches": la["launches"],
                                   "avg_launch_us": round(la["ms"] * 1e3 / la["launches"], 2),
                                   "workload": f"{npv} interchanges x {n} columns, nothing else on the GPU"}
+        if laswp is not None and through_engine:
+            # Inside the shipped schedule of this size the interchanges are not launches of their own: the engine applies them in its
+            # strip units (in front of every block-row solve) and as deferred-interchange units on the finished columns; the launches
+            # timed above are the chain's few-MB per-leaf ones only.  The in-schedule HBM rate of laswp_kernel therefore does not exist
+            # here: the headline figure of this object is the kernel BY ITSELF (`alone`), next to the PMC traffic ratio of the stream
+            # schedule's launches (profiles/: 8.39 GB moved for 8.59 GB algorithmic, no re-reads) and what the engine's own
+            # deferred-interchange units do per workgroup.
+            ins = {k: laswp.pop(k) for k in ("achieved", "frac", "launches", "total_ms", "algorithmic_bytes") if k in laswp}
+            laswp.pop("wide", None)
+            laswp["chain_launches_only"] = {"gb_per_s": ins.get("achieved"), "launches": ins.get("launches"), "total_ms": ins.get("total_ms"),
+                                            "algorithmic_bytes": ins.get("algorithmic_bytes"),
+                                            "note": "the per-leaf launches of the critical path (latency-bound, a few MB each): NOT the factorization's "
+                                                    "interchange traffic, which the engine moves"}
+            if "alone" in laswp:
+                laswp["achieved"] = laswp["alone"]["achieved"]
+                laswp["frac"] = laswp["alone"]["frac"]
+            laswp["note"] = ("engine schedule: achieved / frac = laswp_kernel with the GPU to itself (`alone`); in the schedule the interchanges "
+                             "run inside engine_kernel (strip + deferred-interchange units), see engine_deferred_units")
+            try:   # one traced factorization: workgroup time of the engine's deferred-interchange units (pure row moves)
+                os.environ["RFLU_ENGINE_TRACE"] = "1"
+                h.reload_tuning()
+                regenerate(); barrier(); step(); barrier()
+                acct = (ctypes.c_longlong * 8)()
+                h.call("rflu_debug_engine_acct", acct)
+                esz = 8 if sfx == "f64" else 4
+                W = 512
+                nb = (n + W - 1) // W
+                left_bytes = 4.0 * esz * sum(W * (b * W) for b in range(nb)) + 4.0 * esz * nb * sum((W // 64 - 1 - u) * 64 * 64 for u in range(W // 64))
+                wg_s = acct[3] / 1e8
+                if wg_s > 0:
+                    laswp["engine_deferred_units"] = {"algorithmic_bytes": left_bytes, "workgroup_ms": round(wg_s * 1e3, 2),
+                                                      "gb_per_s_per_workgroup": round(left_bytes / wg_s / 1e9, 2),
+                                                      "share_of_all_interchange_bytes": round(left_bytes / (4.0 * esz * n * n), 3),
+                                                      "note": "RFLU_ENGINE_TRACE=1: time the engine's workgroups spend in deferred-interchange "
+                                                              "units (the interchanges of later block columns on the finished columns to the left: "
+                                                              "half of all interchange bytes), summed over the 448 resident workgroups"}
+            except Exception as e:   # measurement aid only
+                laswp["engine_deferred_units"] = {"error": str(e)}
+            finally:
+                os.environ.pop("RFLU_ENGINE_TRACE", None)
+                h.reload_tuning()
         # BASELINE config 2: the block-size sweep 64 / 128 / 256 at this size (two timed factorizations each)
         if pivot and args.blocksize == 0 and n >= 1024:
             sweep = []

@@ -50,6 +50,37 @@ static void env_flag(const char* name, int& v) { if (env_str(name)) v = 1; }   /
 void Tune::load_env()
 {
     *this = Tune();
+    // ---- the shipped library's surface: schedule selection, the knobs the tests and the measurement scripts
+    // switch, tracing.  Everything below the #ifdef is tuning that was measured once and settled: read by the
+    // experiments build only (RFLU_EXPERIMENTS=1 at BUILD time -> librflu_exp.so), compiled-in defaults otherwise.
+    env_get("RFLU_PANEL_LOCAL_ROWS", panel_local_rows);
+    env_get("RFLU_GEMM_MASKED", gemm_masked);
+    env_get("RFLU_TRSV_MAX_RHS", trsv_max_rhs);
+    env_get("RFLU_TRSM_CHAIN_MAX_RHS", trsm_chain_max_rhs);
+    env_get("RFLU_QUEUE_CHECK", queue_check);
+    env_flag("RFLU_QUEUE_TRACE", queue_trace);
+    env_flag("RFLU_SPLIT_ALL", split_all);
+    env_get("RFLU_SPLIT_SCALE", split_scale);
+    env_get("RFLU_LEAFWISE", leafwise);
+    env_get("RFLU_LEAFWISE_ROWS", leafwise_rows);
+    env_flag("RFLU_GATE_TRACE", gate_trace);
+    if (const char* e = env_str("RFLU_SCHEDULE")) schedule_events = strcmp(e, "events") == 0;
+    // rocprofv3 --pmc exports this into the profiled process and runs one kernel at a time: a device-side gate would only ever
+    // see its timeout, so a counter-collection run takes the event schedule by itself (RFLU_SCHEDULE=gates overrides)
+    else if (env_str("ROCPROF_COUNTER_COLLECTION")) schedule_events = 1;
+    env_get("RFLU_LEAF_FUSE", leaf_fuse);
+    env_get("RFLU_HOST_EARLY_OUT", host_early_out);
+    env_flag("RFLU_HOST_TRACE", host_trace);
+    env_get("RFLU_HOST_THREADS", host_threads);
+    env_get("RFLU_MGPU_BIG_RESERVE", mgpu_big_reserve);
+    env_get("RFLU_DEBUG_GHOST_LEAF", debug_ghost_leaf);
+    env_get("RFLU_ENGINE", engine);
+    env_get("RFLU_ENGINE_ROWS", engine_rows);
+    env_get("RFLU_ENGINE_HOST", engine_host);
+    env_get("RFLU_ENGINE_REPLAY", engine_replay);
+    env_get("RFLU_ENGINE_RETIRE", engine_retire);
+    env_get("RFLU_ENGINE_AHEAD", engine_ahead);
+#ifdef RFLU_EXPERIMENTS
     env_get("RFLU_PANEL_PW", panel_pw);
     env_get("RFLU_PANEL_MAXG", panel_maxg);
     env_get("RFLU_PANEL_RPW", panel_rpw);
@@ -58,7 +89,6 @@ void Tune::load_env()
     env_get("RFLU_PANEL_SPARE_MIN", panel_spare_min);
     env_get("RFLU_PANEL_BALLAST", panel_ballast);
     env_get("RFLU_PANEL_LOCAL_MIN", panel_local_min);
-    env_get("RFLU_PANEL_LOCAL_ROWS", panel_local_rows);
     env_get("RFLU_PANEL_LOCAL_PW8_ROWS", panel_local_pw8_rows);
     env_get("RFLU_POLL_DELAY", poll_delay);
     env_get("RFLU_POLL_ADAPT", poll_adapt);
@@ -67,58 +97,33 @@ void Tune::load_env()
     env_get("RFLU_SKINNY_MAXK", skinny_max_k);
     env_get("RFLU_SKINNY_WIDE", skinny_wide);
     env_get("RFLU_GEMM_CFIRST_BELOW", gemm_cfirst_below);
-    env_get("RFLU_GEMM_MASKED", gemm_masked);
     env_get("RFLU_LD_PAD", ld_pad);
     ld_pad = (ld_pad / 16) * 16;
-    env_get("RFLU_TRSV_MAX_RHS", trsv_max_rhs);
-    env_get("RFLU_TRSM_CHAIN_MAX_RHS", trsm_chain_max_rhs);
     env_get("RFLU_TRSM_CHAIN_SPLIT", trsm_chain_split);
     env_get("RFLU_TRSM_CHAIN_CACHED", trsm_chain_cached);
-    env_get("RFLU_QUEUE_CHECK", queue_check);
-    env_flag("RFLU_QUEUE_TRACE", queue_trace);
-    env_flag("RFLU_SPLIT_ALL", split_all);
     env_get("RFLU_SPLIT_SHARE", split_share);
-    env_get("RFLU_SPLIT_SCALE", split_scale);
     env_get("RFLU_MAX_RESERVE", max_reserve);
     env_get("RFLU_WIDE_NARROW", wide_narrow);
     env_get("RFLU_NARROW_COLS", narrow_cols);
     env_get("RFLU_RESERVE_CUS", min_reserve);
     env_get("RFLU_CONFINE_ROWS", confine_rows);
     env_get("RFLU_MERGE_ROWS", merge_rows);
-    env_get("RFLU_LEAFWISE", leafwise);
-    env_get("RFLU_LEAFWISE_ROWS", leafwise_rows);
     env_get("RFLU_SWAP_SU", swap_su);
-    env_get("RFLU_GATE_FOLD", gate_fold);
-    env_flag("RFLU_GATE_TRACE", gate_trace);
-    if (const char* e = env_str("RFLU_SCHEDULE")) schedule_events = strcmp(e, "events") == 0;
-    // rocprofv3 --pmc exports this into the profiled process and runs one kernel at a time: a device-side gate would only ever
-    // see its timeout, so a counter-collection run takes the event schedule by itself (RFLU_SCHEDULE=gates overrides)
-    else if (env_str("ROCPROF_COUNTER_COLLECTION")) schedule_events = 1;
-    env_flag("RFLU_TIME_ENQUEUE", time_enqueue);
     env_get("RFLU_SWAP_LATE", swap_late);
     env_get("RFLU_SWAP_ROWS", swap_rows);
-    env_get("RFLU_LEAF_FUSE", leaf_fuse);
+    env_get("RFLU_GATE_FOLD", gate_fold);
+    env_flag("RFLU_TIME_ENQUEUE", time_enqueue);
     env_get("RFLU_TAIL_OVERLAP", tail_overlap);
-    env_get("RFLU_HOST_EARLY_OUT", host_early_out);
-    env_flag("RFLU_HOST_TRACE", host_trace);
-    env_get("RFLU_HOST_THREADS", host_threads);
-    env_get("RFLU_MGPU_BIG_RESERVE", mgpu_big_reserve);
     env_get("RFLU_MGPU_TALL_ROWS", mgpu_tall_rows);
     env_get("RFLU_MGPU_SYNC", mgpu_sync);
-    env_get("RFLU_DEBUG_GHOST_LEAF", debug_ghost_leaf);
-    env_get("RFLU_ENGINE", engine);
     env_get("RFLU_ENGINE_POLICY", engine_policy);
     env_get("RFLU_ENGINE_WGS", engine_wgs);
-    env_get("RFLU_ENGINE_ROWS", engine_rows);
-    env_get("RFLU_ENGINE_HOST", engine_host);
-    env_get("RFLU_ENGINE_REPLAY", engine_replay);
     env_get("RFLU_ENGINE_WC", engine_wc);
-    env_get("RFLU_ENGINE_RETIRE", engine_retire);
     env_get("RFLU_ENGINE_WRITE_THROUGH", engine_write_through);
     env_get("RFLU_ENGINE_LEAF_XCDS", engine_leaf_xcds);
     env_get("RFLU_ENGINE_LEAF_WGS", engine_leaf_wgs);
     env_get("RFLU_ENGINE_HOST_LAG", engine_host_lag);
-    env_get("RFLU_ENGINE_AHEAD", engine_ahead);
+#endif
 }
 
 // the handle's own switches (kernel routing) + its Tune
@@ -137,7 +142,9 @@ static void load_handle_env(Handle* h)
     env_get("RFLU_PANEL_SINGLE", h->panel_single);
     env_get("RFLU_PANEL_BLOCKED", h->panel_blocked);
     if (h->panel_local == 1) h->panel_local_maxg = 32;   // one XCD has 32 CUs
+#ifdef RFLU_EXPERIMENTS
     env_get("RFLU_PANEL_LOCAL_MAXG", h->panel_local_maxg);
+#endif
 }
 
 // Leading dimension of the row-major workspace for n columns: a multiple of 16 elements (rows start on 128-byte lines).
@@ -1423,12 +1430,14 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             // the update engine serves the block columns whose panels are taller than engine_rows (the leaf-wise schedule from block
             // column 0, its side / update streams replaced by the engine); below that the streams and the XCD-local leaves take over
             int64_t eng_end = 0;
-            // the engine where asked for (RFLU_ENGINE=1, the host entry) or, by default, where it measures faster than the streams: Float64
-            // with pivoting (a Float32 pivot search may answer the engine's other summation order with another pivot sequence, NoPivot with
-            // visibly other digits), the default block width of 512, i.e. more than 12288 columns (N=16384: 72 vs 75.5 ms; at 256-wide
-            // block columns the streams win: N=12288 44.7 vs 43.7, N=8192 25.7 vs 24.0)
+            // the engine where asked for (RFLU_ENGINE=1, the host entry) or, by default, where it measures faster than the streams: with
+            // pivoting at the default block width of 512, i.e. more than 12288 columns (N=16384 Float64: 72 vs 75 ms, Float32 -- round 6 --
+            // 56.0 vs 58.8; NoPivot: 68.9 vs 64.1, the streams stay; at 256-wide block columns the streams win: N=12288 44.7 vs 43.7, N=8192
+            // 25.7 vs 24.0).  A Float32 pivot search may answer another summation order with another (equally valid) pivot sequence from a
+            // near-tie on -- between the stream schedules too: tests hold Float32 to the residual and a floor of equal
+            // leading pivots, not to the bits of another schedule.
             const bool eng_wanted = h->eng_host_mode || h->tune.engine == 1 || h->tune.engine_replay ||
-                                    (h->tune.engine < 0 && sizeof(T) == 8 && pivot && default_bs && Wb == 512 && mn > 12288 && m >= n);
+                                    (h->tune.engine < 0 && pivot && default_bs && Wb == 512 && mn > 12288 && m >= n);
             if (eng_wanted && leafwise && Wb >= 2 * NB && Wb <= 512 && W_wide == 0 && m <= 32 * (int64_t)PANEL_THREADS && engine_usable<T>(h, f, Wb)) {
                 const int64_t er = h->eng_host_mode ? 0 : std::max<int64_t>(h->tune.engine_rows, 0);   // (host entry: every block column through the engine)
                 eng_end = m <= er ? 0 : std::min(nblk, (m - er + Wb - 1) / Wb);
@@ -2033,7 +2042,9 @@ int rflu_create(rflu_handle_t* handle, int device)
         // and competes for CUs with the bulk trailing update on the second stream
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+#ifdef RFLU_EXPERIMENTS
         if (env_str("RFLU_NO_PRIORITY")) hi = 0;
+#endif
         RFLU_HIP(hipStreamCreateWithPriority(&h->own_stream, hipStreamDefault, hi));
     }
     h->stream = h->own_stream;

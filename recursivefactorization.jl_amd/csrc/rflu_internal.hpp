@@ -114,7 +114,7 @@ struct Tune {
     int debug_ghost_leaf = -1;         // RFLU_DEBUG_GHOST_LEAF
     // persistent update engine (engine.hip): the default schedule where it measures faster than the streams, and the host entry
     int engine = -1;                   // RFLU_ENGINE: 1 = the side / update streams' work is pulled by the resident engine wherever it can be, 0 = never,
-                                       // -1 (default) = where it measures faster: Float64, pivoted, default block width, 12288 < min(m, n), m <= 16384 (N=16384: 72 vs 75.5 ms)
+                                       // -1 (default) = where it measures faster: pivoted, default block width, 12288 < min(m, n), m <= 16384 (N=16384: 72 vs 75 ms, Float32 56.0 vs 58.8)
     int engine_policy = 0;             // RFLU_ENGINE_POLICY: 0 = leftmost column block first, 1 = oldest panel piece first
     int engine_wgs = 0;                // RFLU_ENGINE_WGS: resident workgroups (0: two per CU of the update mask)
     int64_t engine_rows = 0;           // RFLU_ENGINE_ROWS: block columns whose panels are taller than this go through the engine, the streams take over below (0: the engine

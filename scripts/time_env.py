@@ -26,12 +26,15 @@ for r in range(reps + 1):
     for c in cfgs:
         for k in list(os.environ):
             if k.startswith("RFLU_"): del os.environ[k]
+        bs = 0
         for kv in filter(None, c.split(",")):
-            k, v = kv.split("="); os.environ[k] = v
+            k, v = kv.split("=")
+            if k == "BS": bs = int(v)      # (pseudo-variable: the blocksize argument of the call)
+            else: os.environ[k] = v
         h.reload_tuning()
         A = A0.clone(); info = ctypes.c_int64(0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        h.call(f"rflu_getrf_{sfx}_dev", n, n, ctypes.c_void_p(A.data_ptr()), n, ctypes.c_void_p(ip.data_ptr()) if pivot else None, pivot, 0, ctypes.byref(info))
+        h.call(f"rflu_getrf_{sfx}_dev", n, n, ctypes.c_void_p(A.data_ptr()), n, ctypes.c_void_p(ip.data_ptr()) if pivot else None, pivot, bs, ctypes.byref(info))
         torch.cuda.synchronize()
         if r > 0: times[c].append((time.perf_counter() - t0) * 1e3)
         elif c not in res:

@@ -31,8 +31,8 @@ def test_engine_matches_stream_schedule(m, n, bs, dtype, monkeypatch):
     monkeypatch.setenv("RFLU_ENGINE", "0")
     A, F = _factor(n, dtype, True, bs, m=m)
     monkeypatch.setenv("RFLU_ENGINE", "1")
-    for policy in ("0", "1"):
-        monkeypatch.setenv("RFLU_ENGINE_POLICY", policy)
+    for ahead in ("1", "2"):   # leaf windows over the own block column + 1 (default) / 2 block columns right of it (engine.hpp: EngGeo::ahead)
+        monkeypatch.setenv("RFLU_ENGINE_AHEAD", ahead)
         _, G = _factor(n, dtype, True, bs, m=m)
         assert F.info == G.info == 0
         assert rf.last_path() == "hip-engine"
@@ -124,3 +124,20 @@ def test_engine_against_the_cpu_oracle(m, n, bs, monkeypatch):
     if m == n:
         dA = torch.from_numpy(np.ascontiguousarray(A.T)).to("cuda:0").T   # (W was factored in place)
         assert matvec_residual(dA, F.factors, F.ipiv) < 1e-12
+
+
+def test_default_rule_float32_headline_size_goes_through_the_engine(monkeypatch):
+    """Round 6: Float32 pivoted matrices of more than 12288 columns take the engine by default too (N=16384: 56.0 vs 58.8 ms).  Float32 is held
+    to what the reference holds it to -- info, the residual bound (test/runtests.jl:19-20) -- plus a floor of leading pivots equal to the
+    stream schedule's: past a near-tie two valid summation orders may choose different pivots."""
+    n = 16384
+    monkeypatch.setenv("RFLU_ENGINE", "0")
+    A, F = _factor(n, np.float32, True, 0)
+    assert rf.last_path() == "hip-lookahead" and F.info == 0
+    monkeypatch.delenv("RFLU_ENGINE")
+    _, G = _factor(n, np.float32, True, 0)
+    assert rf.last_path() == "hip-engine" and G.info == 0
+    same = (F.ipiv == G.ipiv).cpu().numpy()
+    lead = int(np.argmin(same)) if not same.all() else n
+    assert lead >= 1024, lead
+    assert matvec_residual(A, G.factors, G.ipiv) < 20 * n * np.finfo(np.float32).eps

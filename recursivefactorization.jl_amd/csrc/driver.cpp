@@ -1563,10 +1563,12 @@ static int getrf_host_engine(Handle* h, int64_t m, int64_t n, T* A, int64_t lda,
     const int64_t mn = std::min(m, n);
     const int64_t chunk = h->tune.host_early_out;
     const int64_t W = round_up(blocksize == 0 ? default_blocksize(mn) : blocksize, NB);
-    // Float64 with pivoting only: the engine applies the same eliminations in another summation order than the stream schedules, which
-    // a Float32 pivot search may answer with another (equally valid) pivot sequence and an unpivoted factorization with visibly other
-    // digits -- those keep the stream path, whose host entry is bit-identical to the device entry
-    if (sizeof(T) != 8 || !pivot) return RFLU_OK;
+    // With pivoting only (round 6: Float32 too -- its device entry takes the engine at the headline size as well; a Float32 pivot search may
+    // answer the engine's summation order with another, equally valid pivot sequence than a stream schedule's from a near-tie on, which is
+    // why tests hold Float32 to the residual and a floor of equal leading pivots).  An unpivoted factorization shows another summation order
+    // in visibly other digits and measures slower through the engine (N=16384: 68.9 vs 64.1 ms): it keeps the stream path, whose host entry
+    // is bit-identical to the device entry
+    if (!pivot) return RFLU_OK;
     if (!h->tune.engine_host || h->prof || h->prof_one_stream || h->num_cus != 256 || !h->tune.leafwise || h->tune.schedule_events ||
         chunk < 64 || mn < 8192 || m > 32 * (int64_t)PANEL_THREADS || m < n || W < 2 * NB || W > 512 || W % 128 != 0 || W >= mn ||
         (blocksize == 0 && mn >= 20480))

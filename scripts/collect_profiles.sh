@@ -25,6 +25,7 @@ python scripts/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.c
 python scripts/rocpd_blocks.py $DB 1 > $OUT/blocks.txt 2>/dev/null || true
 python scripts/rocpd_blocks.py $DB 2 > $OUT/blocks2.txt 2>/dev/null || true
 python scripts/rocpd_queues.py $DB 2 > $OUT/queues2.txt 2>/dev/null || true
+python scripts/rocpd_leaves.py $DB 1 8 0:4096 > $OUT/leaves.txt 2>/dev/null || true
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma   # keep the summaries only (gpurun_out is size-limited)
 cat $OUT/kernel_stats.txt | head -30
 cat $OUT/pmc.txt | grep -E "gemm|==" 

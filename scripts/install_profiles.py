@@ -42,6 +42,37 @@ for n, d in ((16384, f"prof_{tag}"), (4096, f"prof_{tag}_n4096")):
             "# leaf-wise part; queue 4 = the 192-CU stream: the updates from the last lookahead block column on (round 4, DESIGN.md section 3.11).\n"
             + rd(d, "blocks.txt"))
 
+# ---- round 6: the chain leaf by leaf, the engine's counters (replayed alone) and its workgroup-time table
+d16 = f"prof_{tag}"
+if os.path.exists(os.path.join(G, d16, "leaves.txt")):
+    open(os.path.join(P, f"{tag}_n16384_leaves.txt"), "w").write(
+        f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}) -- same rocprofv3 --kernel-trace run as {tag}_n16384_kernel_stats.txt, one timed factorization\n"
+        "# (scripts/rocpd_leaves.py): the critical-path queue leaf by leaf.  `lookahead launch` = leaf_la_kernel: ~15-21 us of work (interchanges on the next\n"
+        "# leaf's 64 columns, diagonal inverse, 64-row solve) + the folded wait for the update engine's progress word.  The waiting is at the LAST leaf of every\n"
+        "# block column (g = 8 b + 7): its lookahead strip is the first 64 columns of the NEXT block column, whose column block has to have received BIG(b - 1)\n"
+        "# and then, one two-stage leaf window after the other, the seven leaves of block column b factored meanwhile (DESIGN.md section 7).\n"
+        + rd(d16, "leaves.txt"))
+if os.path.exists(os.path.join(G, d16, "engine_pmc.txt")):
+    open(os.path.join(P, f"{tag}_engine_pmc.txt"), "w").write(
+        f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}) -- the resident engine_kernel REPLAYED ALONE (RFLU_ENGINE_REPLAY=1, scripts/engine_replay.py: a real\n"
+        "# factorization first, then the engine on that image with every leaf counted as done and no chain next to it; same operations, addresses and counts),\n"
+        "# three separate passes: rocprofv3 --kernel-trace --pmc <COUNTERS> -f csv -- python scripts/engine_replay.py 16384 1   (scripts/pmc_engine.sh).\n"
+        "# ONE launch per run.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads -> read bytes = 2*FETCH_SIZE*1024.\n"
+        "# SQ_VALU_MFMA_BUSY_CYCLES sums over the chip's 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs: MFMA-busy share = busy / (1024 * active / 8).\n"
+        + rd(d16, "engine_pmc.txt") + "# kernel durations in the three counter runs (rocpd):\n" + "".join("# " + l for l in open(os.path.join(G, d16, "engine_pmc_durations.txt"))))
+    open(os.path.join(P, f"{tag}_engine_replay.txt"), "w").write(
+        f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}) -- python scripts/engine_replay.py 16384 3 (no profiler): the engine alone on 224 CUs, all-in:\n"
+        "# flops = sum of 2 M N K over its operations, algorithmic_bytes = per operation A and B once, the Schur block in and out, the solved block row in and\n"
+        "# out, the interchanges (driver.cpp: factor_leafwise), engine_ms = HIP event pair around the one launch.  NOTE the replay has a chain of its own: 256 leaf\n"
+        "# windows per column block, two dependent stages each, ~0.2 ms per window -- it is not a pure throughput figure (DESIGN.md section 7).\n"
+        + "".join(l for l in open(os.path.join(G, d16, "engine_replay.txt")) if "amdgpu.ids" not in l))
+if os.path.exists(os.path.join(G, rnd, "engine_trace.txt")):
+    open(os.path.join(P, f"{tag}_engine_workgroup_time.txt"), "w").write(
+        f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}) -- RFLU_ENGINE_TRACE=36:8 python scripts/time_env.py 16384 3: the accounting the engine keeps of its\n"
+        "# 448 workgroups' time by kind of unit (100 MHz clock, summed over the workgroups), and for the leaves 36..43 (block column 4) when LEAF(g) was first claimed on the\n"
+        "# column block of its first columns and -- behind `||` -- on the NEXT block column's first column block: the catch-up behind BIG(b - 1) the chain's last leaf waits for.\n"
+        + "".join(l for l in open(os.path.join(G, rnd, "engine_trace.txt")) if "amdgpu.ids" not in l))
+
 # ---- size table
 rows = []
 for f in sorted(os.listdir(os.path.join(G, rnd))):
@@ -83,7 +114,9 @@ block("# host-pointer entry (scripts/microbench_host_entry.py, one caller buffer
 block("# cooperative leaf alone on the GPU (scripts/panel_bench.py, mode 2 = shipped kernel):", "panel_bench.txt", keep="mode 2")
 block("# solve step ldiv!(F, B) on row-major device factors (scripts/microbench_getrs.py):", "getrs.txt")
 block("# blocks of right-hand sides: the cooperative MFMA chain against the recursive splitting (scripts/getrs_check.py):", "getrs_block.txt")
-block("# the persistent update engine against the stream schedule (scripts/engine_check.py time; best of 4, ms):", "engine_time.txt")
+block("# the persistent update engine against the stream schedule and its own variants (scripts/time_env.py: alternating in one process, best / median of 4, ms):", "engine_time.txt")
 block("# cooperative leaf alone: any placement (mode 2, shipped routing above 4096 rows) against XCD-local (mode 1) (scripts/panel_bench.py):", "panel_bench_local.txt")
+block("# one block column of a tall matrix by itself = the owner's panel of the multi-GPU driver (scripts/tall_panel.py):", "tall_panel.txt")
+block("# liveness (scripts/engine_stress.py):", "engine_stress.txt")
 open(os.path.join(P, f"{tag}_sizes.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out[:16]))

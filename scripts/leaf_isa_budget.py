@@ -54,8 +54,12 @@ show("row waves, column 32: barrier A -> barrier B (hand-over read, two chain mu
 show("row waves, column 32: barrier B -> barrier A of column 33 (the rest of elimination 31: 31 multiply-adds per row, row record of the candidate's owner)", b32, a33)
 a8, b8, a9 = tail[2 * 8], tail[2 * 8 + 1], tail[2 * 9]
 show("row waves, column 8: barrier B -> barrier A of column 9 (55 multiply-adds per row)", b8, a9)
-# communication wave: everything between the first barrier of the kernel and the first barrier of the unrolled tail that is inside a loop
+# communication wave: a run-time loop { barrier B(c - 1); combine + publish + pause + poll + reduce + divide + hand over; barrier A(c) } in front of the
+# unrolled row-wave code: the last two barriers in front of the unrolled tail are B and A of the loop body (static count: the poll loop's body once)
 head_bar = [b for b in bar if b < tail[0]]
-if len(head_bar) >= 3:
-    show("communication wave, loop body: barrier B -> barrier A (combine the wave records, publish the header, poll the G headers, reduce, divide, hand over)", head_bar[-3], head_bar[-2])
-    show("communication wave, loop body: barrier A -> barrier B (waits for the row waves)", head_bar[-2], head_bar[-1])
+if len(head_bar) >= 2:
+    show("communication wave, loop body: barrier B -> barrier A (combine the PW wave records, publish the header, pause, ONE poll round for the G headers and the winner's row record, finish the lagging entries, reduce, divide, hand over; the poll loop's body counted once)", head_bar[-2], head_bar[-1])
+print("# the five things the algorithm needs per column and row wave: |a| compare (the integer-key argmax: 6 DPP steps + 1 readlane on the fast path; ties add 12 DPP steps), the")
+print("# reciprocal (communication wave only: every lane divides for its own header while the reduction runs), one multiply (l = a * 1/pivot), and the multiply-adds of the rank-1")
+print("# update: 2 on the chain (A -> B), the other <= 61 per row between B and the next A, next to the exchange.  Everything else in the A -> B segment is control: the 48-byte hand-over")
+print("# read (3 ds_read_b128), position bookkeeping (v_cmp / v_cndmask pairs), s_nop padding between DPP steps, exec-mask moves.")

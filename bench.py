@@ -689,8 +689,8 @@ def main():
             host_entry = {"host_to_host_ms": round(1e3 * hh, 2), "factor_ms": round(ms_per_step, 3),
                           "pcie_bytes_each_way": esz * n * n,
                           "note": "rflu_getrf_* on a pageable host array (lu! of a host matrix): copy in, factor, factors and ipiv back in "
-                                  "the caller's array; best of two warm calls, wall clock around the call.  Float64 pivoted square / tall "
-                                  "8192..16384: the matrix arrives block column by block column WHILE it is factored (driver.cpp: "
+                                  "the caller's array; best of two warm calls, wall clock around the call.  Pivoted square / tall "
+                                  "8192..16384 (Float64 and, since round 6, Float32): the matrix arrives block column by block column WHILE it is factored (driver.cpp: "
                                   "getrf_host_engine, the persistent update engine of csrc/engine.hip), rows leave as they become final"}
             del keep, Ah
 

@@ -123,6 +123,7 @@ void Tune::load_env()
     env_get("RFLU_ENGINE_LEAF_XCDS", engine_leaf_xcds);
     env_get("RFLU_ENGINE_LEAF_WGS", engine_leaf_wgs);
     env_get("RFLU_ENGINE_HOST_LAG", engine_host_lag);
+    env_get("RFLU_ENGINE_SOLVE_RL", engine_solve_rl);
 #endif
 }
 
@@ -1066,6 +1067,7 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
         a.write_through = h->tune.engine_write_through != 0;
         a.leaf_xcds = h->tune.engine_leaf_xcds;
         a.leaf_wgs = h->tune.engine_leaf_wgs;
+        a.solve_rl = h->tune.engine_solve_rl != 0;
         // host entry: whole-block-column operations that lag the chain by this many block columns go first (engine.hip), so that
         // block rows become final -- and leave -- while the factorization runs
         a.host_lag = h->eng_host_mode ? h->tune.engine_host_lag : 0;

@@ -86,6 +86,7 @@ struct EngUnit {
     EngGeo g;
     int gemm_flags;
     int write_through;
+    int solve_rl;
 };
 template <typename T>
 __device__ __forceinline__ EngUnit<T> eng_unit_args(const EngArgs<T>& a, T* smem)
@@ -101,6 +102,7 @@ __device__ __forceinline__ EngUnit<T> eng_unit_args(const EngArgs<T>& a, T* smem
     u.g = a.g;
     u.gemm_flags = a.gemm_flags;
     u.write_through = a.write_through;
+    u.solve_rl = a.solve_rl;
     return u;
 }
 
@@ -138,6 +140,122 @@ __device__ __attribute__((noinline)) void eng_prep_unit(const EngUnit<T> a, cons
     const int fi = lane & 15, fk = lane >> 4;
     const int arow = wave * 16 + fi;
     T* Xd = smem;
+    constexpr int EP_MAXBLK = 8;   // block rows of up to 8 x 64 = 512 rows take the right-looking walk
+    if (nblk <= EP_MAXBLK && a.solve_rl) {
+        // RIGHT-looking over the 64-row blocks, the whole block row in registers (round 6).  The left-looking walk below read the solved
+        // blocks X_e back from memory for every later block d -- per block a store, a wait for its acknowledgement, a barrier and a round of
+        // dependent loads: ~16 us x 8 blocks for a 512-row block row, the longest unit of the engine and stage 0 of every whole-block-column
+        // operation on every column block's sequential list (strips + solves made free are worth 6 ms of 72.7 at N=16384: DESIGN.md section
+        // 9).  Here wave w holds ITS 16 rows of all (up to) 8 blocks (8 x 2 accumulators = 128 VGPRs for Float64), X_d goes from the inverse
+        // product to LDS and straight into the updates B_e -= L_ed X_d of the blocks below; L's blocks do not depend on X, so their loads are
+        // free to run ahead.  Every accumulator receives the same products in the same order as before (for a fixed block: d ascending):
+        // bit-identical.
+        acc_t acc[EP_MAXBLK][2];
+#pragma unroll
+        for (int e = 0; e < EP_MAXBLK; ++e) {
+            const int rows_e = e < nblk ? min(NB, jb - e * NB) : 0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wave * 16 + Mfma<T>::crow(lane, r);
+                    const int col = t * 16 + fi;
+                    acc[e][t][r] = (row < rows_e && col < nc) ? B[(int64_t)(e * NB + row) * ld + col] : T(0);
+                }
+        }
+        // L rows of block e for the update with X_d (negated), and the rows of the inverted diagonal block d: both independent of the
+        // solve's results, requested a step ahead of their use
+        auto load_l = [&](T (&av)[16], int e, int d) {
+            const bool rok = arow < min(NB, jb - e * NB);
+            const T* Lp = L + (int64_t)(e * NB + arow) * ld + d * NB + 16 * fk;
+            if (rok) {
+                typedef T ep_vec __attribute__((ext_vector_type(VW)));
+#pragma unroll
+                for (int v = 0; v < 16 / VW; ++v) {
+                    const ep_vec y = *reinterpret_cast<const ep_vec*>(Lp + v * VW);
+#pragma unroll
+                    for (int q = 0; q < VW; ++q) av[v * VW + q] = -y[q];
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) av[kk] = T(0);
+            }
+        };
+        auto load_inv = [&](T (&ai)[16], int d) {
+            const T* Ip = Linv + (int64_t)d * NB * NB + arow * NB + 16 * fk;
+            typedef T ep_vec __attribute__((ext_vector_type(VW)));
+#pragma unroll
+            for (int v = 0; v < 16 / VW; ++v) {
+                const ep_vec x = *reinterpret_cast<const ep_vec*>(Ip + v * VW);
+#pragma unroll
+                for (int q = 0; q < VW; ++q) ai[v * VW + q] = x[q];
+            }
+        };
+        auto mul_l = [&](const T (&av)[16], acc_t (&c)[2]) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                c[0] = Mfma<T>::run(av[kk], Xd[(16 * fk + kk) * EP_XLD + fi], c[0]);
+                c[1] = Mfma<T>::run(av[kk], Xd[(16 * fk + kk) * EP_XLD + 16 + fi], c[1]);
+            }
+        };
+        // (Float64: 128 VGPRs of accumulators + two L images leave no room to keep the next inverse rows in flight as well -- requested at the
+        // top of their step instead; Float32 has the registers)
+        constexpr bool PRE_INV = sizeof(T) == 4;
+        T ai[16], avA[16], avB[16];
+        if (PRE_INV) load_inv(ai, 0);
+#pragma unroll
+        for (int d = 0; d < EP_MAXBLK; ++d) {
+            if (d < nblk) {   // (workgroup-uniform)
+                const int rows_d = min(NB, jb - d * NB);
+                if (!PRE_INV) load_inv(ai, d);
+                if (d + 1 < nblk) load_l(avA, d + 1, d);   // (the first block below: in flight during the inverse product)
+                // stage this wave's rows of block d as a B operand, then X_d = inv(L_dd) * (what the block has become)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Xd[(wave * 16 + Mfma<T>::crow(lane, r)) * EP_XLD + t * 16 + fi] = acc[d][t][r];
+                __syncthreads();
+                acc_t x[2] = {acc_t{T(0), T(0), T(0), T(0)}, acc_t{T(0), T(0), T(0), T(0)}};
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const T q0 = Xd[(16 * fk + kk) * EP_XLD + fi];
+                    const T q1 = Xd[(16 * fk + kk) * EP_XLD + 16 + fi];
+                    x[0] = Mfma<T>::run(ai[kk], q0, x[0]);
+                    x[1] = Mfma<T>::run(ai[kk], q1, x[1]);
+                }
+                if (PRE_INV && d + 1 < nblk) load_inv(ai, d + 1);   // (the next diagonal block's inverse: in flight during the updates)
+                __syncthreads();   // (everybody has read the staged block: it may become X_d)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = wave * 16 + Mfma<T>::crow(lane, r);
+                        const int col = t * 16 + fi;
+                        const bool in = row < rows_d && col < nc;
+                        if (in) B[(int64_t)(d * NB + row) * ld + col] = x[t][r];
+                        Xd[row * EP_XLD + col] = in ? x[t][r] : T(0);
+                    }
+                if (d + 1 < nblk) {
+                    __syncthreads();
+                    // the blocks below: B_e -= L_ed * X_d (slot (fk, kk) of the MFMA stands for k = 16 fk + kk: a lane's 16 entries of L are
+                    // 128 contiguous bytes of its row).  Two register images of L rows in rotation: block e + 1 is requested before block e is
+                    // multiplied (the compiler's wait counts leave the younger request in flight)
+#pragma unroll
+                    for (int e = d + 1; e < EP_MAXBLK; e += 2) {
+                        if (e < nblk) {
+                            if (e + 1 < nblk) load_l(avB, e + 1, d);
+                            mul_l(avA, acc[e]);
+                            if (e + 2 < nblk) load_l(avA, e + 2, d);
+                            if (e + 1 < nblk) mul_l(avB, acc[e + 1 < EP_MAXBLK ? e + 1 : e]);
+                        }
+                    }
+                    __syncthreads();   // (X_d has been read by everybody: the next block may be staged)
+                }
+            }
+        }
+        return;
+    }
+    // (block rows of more than 512 rows: the left-looking walk, X_e read back from memory)
     for (int d = 0; d < nblk; ++d) {
         const int rows_d = min(NB, jb - d * NB);
         acc_t acc[2];
@@ -581,19 +699,24 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                 const unsigned long long dd = __hip_atomic_fetch_add(&c->done, 1ull + (first_col ? 1ull << 32 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
                                               1ull + (first_col ? 1ull << 32 : 0ull);
                 const unsigned long long d = dd & 0xffffffffull;
+                // Publications carry no release fence (round 6: each used to start with an ACQ_REL fence and publish through four RELEASE
+                // atomics -- an L2 write-back of this XCD in front of every one of them, on the path every stage of every column block's
+                // sequence goes through).  None is needed: whatever a unit wrote is at the memory side BEFORE its count (tiles are stored
+                // write-through and acknowledged, strips are released by their own workgroup), the workgroup that sees the last count only
+                // announces it, and the consumers take their units with an acquire (same box, alternating: N=12288 through the engine 45.2 -> 44.0
+                // ms, Float32 N=16384 55.3 -> 54.9, Float64 N=16384 unchanged).  What has to hold is the ORDER of the publisher's own words:
+                // the counter reads zero before the next sequence can be counted, and the epoch moves after everything it announces.
                 if (first_col && (int)(dd >> 32) == tiles_m && (int)d != units) {
-                    // the window's first tile column is complete: the critical path may go on (prog = 2 * completed ops + 1)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                    // (a maximum, not a store: the workgroup that completes the whole sequence may publish 2 * (op + 1) BEFORE this one, delayed
-                    // between its count and this line, gets here -- a plain store would take the word back to 2 * op + 1 for good)
-                    __hip_atomic_fetch_max(&c->prog, 2ull * (unsigned long long)(seq >> 1) + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    // the window's first tile column is complete: the critical path may go on (prog = 2 * completed ops + 1).  A maximum, not a
+                    // store: the workgroup that completes the whole sequence may publish 2 * (op + 1) BEFORE this one, delayed between its
+                    // count and this line, gets here -- a plain store would take the word back to 2 * op + 1 for good
+                    __hip_atomic_fetch_max(&c->prog, 2ull * (unsigned long long)(seq >> 1) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if ((int)d == units) {
                     if (a.trace && o.type == ENG_OP_LEAF && cb == (o.j0 + o.jb + NB) / a.g.Wc)
                         a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
                     if (a.trace && o.type == ENG_OP_LEAF && cb == eng_first_cb(a.g, o.j0 / a.g.W + 1) && o.j0 / NB < 2048)
                         a.trace[(2048 + o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                     eng_store(&c->done, 0ull);
                     const unsigned end = 2u * (unsigned)eng_nops(a.g, cb);
                     unsigned ns = seq + 1;
@@ -602,22 +725,23 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     if ((ns >> 1) != (seq >> 1)) {
                         for (unsigned k = seq >> 1; k < (ns >> 1); ++k)   // (the operations just completed, skipped ones included)
                             if ((int)k < eng_nbig(a.g, cb))
-                                __hip_atomic_fetch_add(&st->cb[eng_first_cb(a.g, (int)k)].bigdone, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_max(&c->prog, 2ull * (unsigned long long)(ns >> 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_fetch_add(&st->cb[eng_first_cb(a.g, (int)k)].bigdone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_max(&c->prog, 2ull * (unsigned long long)(ns >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (ns >= end) {
-                        __hip_atomic_store(&c->claim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        eng_store(&c->claim, (unsigned long long)ENG_SEQ_DONE << 32);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (whoever reads remaining == 0 finds every claim word closed)
+                        __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
-                        __hip_atomic_store(&c->claim, (unsigned long long)ns << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        eng_store(&c->claim, (unsigned long long)ns << 32);
                     }
-                    __hip_atomic_fetch_add(&st->epoch, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(&st->epoch, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             } else {
                 const int units = eng_left_units<T>(a.g, cb, (int)seq);
                 const unsigned long long d = __hip_atomic_fetch_add(&c->ldone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
                 if ((int)d == units) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                     eng_store(&c->ldone, 0ull);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const int nleft = eng_nleft(a.g, cb);
@@ -626,15 +750,17 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
                     const int pbl = eng_pb(a.g, cb);
                     for (int k = (int)seq; k < nk; ++k)   // the left ops just completed (k = 0: this block column's own interchanges; k >= 1:
                         __hip_atomic_fetch_add(&st->cb[eng_first_cb(a.g, pbl + k)].leftdone, k == 0 ? 1ull << 32 : 1ull,   // block column pbl + k has reached it)
-                                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&c->lprog, (unsigned long long)nk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    eng_store(&c->lprog, (unsigned long long)nk);
                     if (nk >= nleft) {
-                        __hip_atomic_store(&c->lclaim, (unsigned long long)ENG_SEQ_DONE << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        eng_store(&c->lclaim, (unsigned long long)ENG_SEQ_DONE << 32);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
-                        __hip_atomic_store(&c->lclaim, (unsigned long long)nk << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        eng_store(&c->lclaim, (unsigned long long)nk << 32);
                     }
-                    __hip_atomic_fetch_add(&st->epoch, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(&st->epoch, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }

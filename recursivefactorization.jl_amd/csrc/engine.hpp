@@ -250,6 +250,7 @@ struct EngArgs {
     int write_through;   // Schur tiles stored write-through (sc1): no agent-scope release -- an L2 write-back -- behind a tile
     int leaf_xcds;       // the workgroups with blockIdx % 8 in [1, leaf_xcds] and blockIdx / 8 < leaf_wgs serve the leaf windows (K = 64) only
     int leaf_wgs;
+    int solve_rl;        // block-row solves of up to 512 rows right-looking with the block row in registers (engine.hip: eng_prep_unit)
     int host_lag;        // host entry: whole-block-column operations that lag the chain by this many block columns go first (0: never)
     int retire_xcc; // the workgroups on this XCC leave once retire_leaf leaves are done (-1: nobody retires): the short panels at the end, which
     int retire_leaf; // the engine has little to do for, get the XCD their XCD-local exchange needs (driver.cpp: factor_leafwise)

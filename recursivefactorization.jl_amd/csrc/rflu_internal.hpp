@@ -131,6 +131,8 @@ struct Tune {
     int engine_leaf_wgs = 16;          //   leaf windows (K = 64) only: what the chain waits for never queues behind 127-us tiles (N=16384: 97 -> 84 ms; xcds 0: none)
     int engine_ahead = 1;              // RFLU_ENGINE_AHEAD: a leaf is applied leaf by leaf (K = 64) to its own block column and to this many block columns right of it
                                        // (engine.hpp: EngGeo::ahead; 1 = the stream schedule's window: the chain then waits 0.4 .. 2.5 ms at the last leaf of every block column)
+    int engine_solve_rl = 1;           // RFLU_ENGINE_SOLVE_RL (experiments build): the engine's block-row solves right-looking, the block row in registers (0: left-looking,
+                                       // X read back from memory; same box, alternating: N=16384 72.0-72.3 vs 72.8-73.1 ms, bit-identical)
     int engine_host_lag = 5;           // RFLU_ENGINE_HOST_LAG: host entry: whole-block-column operations that lag the chain by this many block columns go first, so
                                        // that block rows become final -- and leave -- while the factorization runs (N=16384: 3: 123 ms, 5: 109-110, 8: 112, 0 = never: 118)
     void load_env();                   // driver.cpp

@@ -1109,6 +1109,11 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                     if (tot > 0)
                         fprintf(stderr, "[rflu] engine workgroup time (previous call, %.1f workgroup-ms): block-column tiles %.1f %%, leaf-window tiles %.1f %%, strips + solves %.1f %%, deferred interchanges %.1f %%, between units %.1f %% (of which asleep with nothing eligible %.1f %%, count + publication behind a unit %.1f %%, scan / claim / acquire %.1f %%)\n",
                                 tot / 1e5, 100.0 * ac[0] / tot, 100.0 * ac[1] / tot, 100.0 * ac[2] / tot, 100.0 * ac[3] / tot, 100.0 * ac[4] / tot, 100.0 * ac[5] / tot, 100.0 * ac[6] / tot, 100.0 * (ac[4] - ac[5] - ac[6]) / tot);
+                    if (tot > 0 && ac[15] > 0)   // the scan by itself, per call (= per unit), in microseconds
+                        fprintf(stderr, "[rflu] engine scan (previous call, %lld calls, %.2f sweeps per call), us per call: epoch / gate sample %.2f, exit words %.2f, claim words + choice %.2f, ticket %.2f, "
+                                        "scan of the deferred interchanges %.2f, acquire + hand-over %.2f; asleep %.2f\n",
+                                ac[15], (double)ac[14] / ac[15], ac[8] / 100.0 / ac[15], ac[9] / 100.0 / ac[15], ac[10] / 100.0 / ac[15], ac[11] / 100.0 / ac[15], ac[12] / 100.0 / ac[15],
+                                ac[13] / 100.0 / ac[15], ac[5] / 100.0 / ac[15]);
                 }
                 // leaf by leaf (RFLU_ENGINE_TRACE=first:count): when LEAF(g) was first claimed on the column block of its first columns (ms since LEAF(0)'s first
                 // claim), its three phases, and how long that column block had been idle before (the engine waiting for the chain) -- for the LAST

@@ -46,13 +46,24 @@ __device__ __forceinline__ int eng_units(const EngArgs<T>& a, int cb, unsigned s
     return eng_units_of(eng_op(a.g, cb, (int)(seq >> 1)), (int)(seq & 1u), a.g.m);
 }
 
+// (the control words live in global memory; said explicitly, because a pointer that reaches a non-inlined function through a structure is a
+// generic one, and generic accesses are flat instructions: slower, and counted on the LDS counter as well)
+typedef unsigned long long __attribute__((address_space(1))) EngGWord;
 __device__ __forceinline__ unsigned long long eng_load(const unsigned long long* p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((const EngGWord*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void eng_store(unsigned long long* p, unsigned long long v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((EngGWord*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long eng_add(unsigned long long* p, unsigned long long v)
+{
+    return __hip_atomic_fetch_add((EngGWord*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void eng_max(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_fetch_max((EngGWord*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void eng_release()
 {
@@ -419,21 +430,43 @@ __device__ __attribute__((noinline)) void eng_left_unit(const EngUnit<T> a, int 
 
 enum { ENG_NONE = 0, ENG_MAIN = 1, ENG_LEFT = 2, ENG_EXIT = 3 };
 
-template <typename T>
-__global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
+// LDS words shared by the kernel and its scan function (static, in front of the dynamic tile buffers)
+__shared__ int eng_sel[4];        // what wave 0 selected: kind, column block, sequence, unit
+__shared__ int eng_wst[4];        // wave 0's own state between two scans: cb_lo, fin_b, column block and sequence of its last unit
+__shared__ long long eng_nap;     // (accounting instantiation) time asleep with nothing eligible
+__shared__ long long eng_ph[8];   // (accounting instantiation) the scan, phase by phase: [0] epoch / gate sample, [1] exit words, [2] claim words + choice, [3] ticket
+                                  // (+ waiting for a later stage's leaves), [4] scan of the deferred interchanges, [5] acquire + hand-over, [6] sweeps, [7] calls
+#define ENG_PH(k) do { if (TRACE && lane == 0) { const long long t_ = wall_clock64(); eng_ph[k] += t_ - ph_t; ph_t = t_; } } while (0)
+
+// ---- the scheduler: wave 0 of a workgroup looks for its next unit and takes it ------------------------------------------------------------
+// A function of its own, NOT inlined (round 6): inside the kernel its values lived across the calls of the unit functions (256 VGPRs each), and
+// the register allocator answered with scratch reloads all along the scan -- every one of them a trip to memory behind a tile that has just
+// streamed the caches empty, on the path every unit of every stage waits for.  Here it has the register file to itself; the arguments are read
+// from the kernel's argument segment (scalar loads), the state it keeps between two calls sits in four LDS words.
+template <typename T, bool TRACE>
+__device__ __attribute__((noinline)) void eng_scan(unsigned long long kernarg)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char eng_smem_raw[];
-    T* smem = reinterpret_cast<T*>(eng_smem_raw);
-    const EngUnit<T> ua = eng_unit_args<T>(a, smem);
-    __shared__ int s_sel[4];   // kind, column block, sequence, unit
+    // (the kernel's argument segment; the address arrives in a vector register pair like every function argument: made scalar again so that
+    // the fields are read with scalar loads)
+    const unsigned long long ku = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(kernarg >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)kernarg);
+    EngArgs<T> a;
+    {
+        static_assert(sizeof(EngArgs<T>) % 4 == 0, "copied word by word");
+        const __attribute__((address_space(4))) unsigned* kp = (const __attribute__((address_space(4))) unsigned*)ku;
+        unsigned* ad = reinterpret_cast<unsigned*>(&a);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(EngArgs<T>) / 4); ++i) ad[i] = kp[i];
+    }
     EngState* const st = a.st;
-    const int tid = threadIdx.x, lane = tid & 63;
-    int cb_lo = 0;             // column blocks in front of this one have nothing left for the main scan (monotone)
-    int fin_b = 0;             // workgroup 0: block rows [0, fin_b) have been reported final (EngArgs::rows_final)
+    const int lane = threadIdx.x & 63;
+    int cb_lo = eng_wst[0];          // column blocks in front of this one have nothing left for the main scan (monotone)
+    int fin_b = eng_wst[1];          // workgroup 0: block rows [0, fin_b) have been reported final (EngArgs::rows_final)
+    const int last_cb = eng_wst[2];  // the stage this workgroup's last unit belonged to (-1: none)
+    const unsigned last_seq = (unsigned)eng_wst[3];
     unsigned my_xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 7u;
-    if (tid == 0) __hip_atomic_fetch_add(&st->xcc_wgs[my_xcc], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool may_retire = a.retire_leaf > 0 && (int)my_xcc == a.retire_xcc;
     // The workgroups that serve the leaf windows only (K = 64: what the chain of leaves waits for finds a free workgroup at once instead of
     // queueing behind 127-us tiles of the block-column updates): those with blockIdx % 8 in [1, leaf_xcds] and blockIdx / 8 < leaf_wgs --
@@ -463,219 +496,343 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         return v > a.gate_base ? (int)(v - a.gate_base) : 0;
     };
 
-    // measurement (RFLU_ENGINE_TRACE): where a workgroup's time goes -- [0] whole-block-column tiles, [1] leaf-window tiles, [2] strips + solves,
-    // [3] deferred interchanges, [4] everything between two units (scan, claim, waiting, completion), summed over the workgroups
-    int last_cb = -1;          // (wave 0) the stage this workgroup's last unit belonged to
-    unsigned last_seq = 0;
-    long long acct[7] = {0, 0, 0, 0, 0, 0, 0};   // ([6]: of [4], from the end of a unit to its count / publication being out)   // ([5]: of [4], the part spent asleep with nothing eligible)
-    long long acct_t = a.trace ? wall_clock64() : 0;
-    for (;;) {
-        if (tid < 64) {
-            int kind = ENG_NONE, sel_cb = 0, sel_unit = 0;
-            unsigned sel_seq = 0;
-            // ---- host entry: how many rows of the factors are final (workgroup 0 looks once per round).  Block row b is final when
-            // nothing will write to it any more: every operation on column block b is complete, the leaves of block column b have
-            // reached column block b + 1, BIG(b) is complete everywhere, and the interchanges of block column b have reached its own
-            // columns and every column block to its left (later block columns only move rows below)
-            if (a.rows_final && blockIdx.x == 0 && fin_b < a.g.nbp) {
-                for (;;) {
-                    const int b = fin_b;
-                    if (b >= a.g.nbp) break;
-                    const int fb = eng_first_cb(a.g, b);
-                    bool fin = leaves_done() >= b * (a.g.W / NB) + eng_leaves_of_block(a.g, b) && leaf_ops_complete(b) &&
-                               (int)eng_load(&st->cb[fb].bigdone) >= eng_big_users(a.g, b);
-                    if (fin && a.g.pivot) {
-                        const unsigned long long ld = eng_load(&st->cb[fb].leftdone);
-                        fin = (int)(ld & 0xffffffffull) >= fb && (!eng_big_waits_for_left(a.g, b) || (int)(ld >> 32) >= eng_cbs_of_block(a.g, b));
-                    }
-                    if (!fin) break;
-                    fin_b = b + 1;
-                    if (lane == 0) {
-                        const int rows = fin_b >= a.g.nbp && a.g.nbp * a.g.W >= a.g.mn ? a.g.m : min(fin_b * a.g.W, a.g.m);
-                        // (the last block row takes the rows below the square part along: nothing writes them after the last panel)
-                        __hip_atomic_store(a.rows_final, (unsigned long long)rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                }
+    int kind = ENG_NONE, sel_cb = 0, sel_unit = 0;
+    unsigned sel_seq = 0;
+    long long ph_t = TRACE ? wall_clock64() : 0;
+    if (TRACE && lane == 0) eng_ph[7] += 1;
+    // ---- host entry: how many rows of the factors are final (workgroup 0 looks once per round).  Block row b is final when
+    // nothing will write to it any more: every operation on column block b is complete, the leaves of block column b have
+    // reached column block b + 1, BIG(b) is complete everywhere, and the interchanges of block column b have reached its own
+    // columns and every column block to its left (later block columns only move rows below)
+    if (a.rows_final && blockIdx.x == 0 && fin_b < a.g.nbp) {
+        for (;;) {
+            const int b = fin_b;
+            if (b >= a.g.nbp) break;
+            const int fb = eng_first_cb(a.g, b);
+            bool fin = leaves_done() >= b * (a.g.W / NB) + eng_leaves_of_block(a.g, b) && leaf_ops_complete(b) &&
+                       (int)eng_load(&st->cb[fb].bigdone) >= eng_big_users(a.g, b);
+            if (fin && a.g.pivot) {
+                const unsigned long long ld = eng_load(&st->cb[fb].leftdone);
+                fin = (int)(ld & 0xffffffffull) >= fb && (!eng_big_waits_for_left(a.g, b) || (int)(ld >> 32) >= eng_cbs_of_block(a.g, b));
             }
-            // a ticket (the value a fetch-and-add on column block cb's claim word returned): this workgroup's unit if the unit exists
-            auto accept = [&](int cb, unsigned long long w) {
-                const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
-                if (seq == ENG_SEQ_DONE) return;
-                const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
-                if ((int)u >= eng_units_of(o, (int)(seq & 1u), a.g.m)) return;   // (past the end: nobody's)
-                kind = ENG_MAIN; sel_cb = cb; sel_seq = seq; sel_unit = (int)u;
-                // The scan saw an eligible sequence; the add may have landed in a LATER one (published in between).  A later
-                // stage 1 is ready by construction; a later stage 0 needs its leaves -- practically never the case (a whole
-                // sequence would have to complete between this wave's scan and its add), but then the claim is held until
-                // they are there (bounded; the leaves do not depend on this workgroup)
-                if ((seq & 1u) == 0) {
-                    const long long t0 = wall_clock64();
-                    const bool wl = o.type == ENG_OP_BIG && eng_big_waits_for_left(a.g, (int)(seq >> 1));
-                    while ((leaves_done() < o.need ||
-                            (wl && (int)(eng_load(&st->cb[eng_first_cb(a.g, (int)(seq >> 1))].leftdone) >> 32) < eng_cbs_of_block(a.g, (int)(seq >> 1)))) &&
-                           eng_load(&st->abort) == 0) {
-                        __builtin_amdgcn_s_sleep(16);
-                        if (wall_clock64() - t0 > 400000000LL) break;   // (the idle timeout of the others raises the flag)
-                    }
-                }
-            };
-            for (int attempt = 0; kind == ENG_NONE; ++attempt) {
-                // what this sweep is based on: if it finds nothing, the wave sleeps on these three words until one of them moves
-                const unsigned long long seen_epoch = eng_load(&st->epoch), seen_gate = eng_load(a.leaf_gate);
-                const unsigned long long seen_arr = a.arrived ? eng_load(a.arrived) : 0ull;
-                // (the three words must have been SAMPLED before anything the sweep looks at is requested: loads to different channels
-                // are served in any order, and a sweep older than the epoch it is paired with sleeps through the publication it missed.
-                // That includes the count of unfinished column blocks: read in front of the epoch, the last publication of a
-                // factorization could fall between the two reads -- the workgroup then slept on the final epoch of a finished
-                // factorization and raised the timeout flag 4 s later: one call in ~200 at N=8192, scripts/engine_stress.py)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0) { kind = ENG_EXIT; break; }
-                const int pd = seen_gate > a.gate_base ? (int)(seen_gate - a.gate_base) : 0;
-                const int have = a.arrived ? (int)seen_arr : a.g.n;   // columns in place (host entry: they arrive while we run)
-                // the chain has reached its short panels: the workgroups on ITS XCD go home (one count each, the critical path waits for the sum)
-                if (may_retire && pd >= a.retire_leaf) {
-                    if (lane == 0) __hip_atomic_fetch_add(&st->retired, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    kind = ENG_EXIT;
-                    break;
-                }
-                // ---- main units: one lane per column block -----------------------------------------------------------------
-                int best = INT_MAX;
-                int first_live = INT_MAX;
-                for (int base = cb_lo & ~63; base < a.g.ncb; base += 64) {
-                    const int cb = base + lane;
-                    int key = INT_MAX;
-                    bool live = false;
-                    if (cb < a.g.ncb) {
-                        const unsigned long long w = eng_load(&st->cb[cb].claim);
-                        const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
-                        if (seq != ENG_SEQ_DONE) {
-                            live = true;
-                            const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
-                            bool ok = o.need <= pd && (int)u < eng_units_of(o, (int)(seq & 1u), a.g.m) && min(a.g.n, (cb + 1) * a.g.Wc) <= have;
-                            if (leaf_only && o.type == ENG_OP_BIG) ok = false;
-                            // a block column as a whole is applied with ITS interchanges complete on all its columns (engine.hpp)
-                            if (ok && o.type == ENG_OP_BIG && (seq & 1u) == 0 && eng_big_waits_for_left(a.g, (int)(seq >> 1)))
-                                ok = (int)(eng_load(&st->cb[eng_first_cb(a.g, (int)(seq >> 1))].leftdone) >> 32) >= eng_cbs_of_block(a.g, (int)(seq >> 1));
-                            if (ok) {
-                                key = a.policy ? (((o.j0 / NB) << 10) | cb) : ((1 << 24) | cb);
-                                // host entry: a block row can leave only when the panel has reached EVERY column block; with the
-                                // leftmost-first rule alone the far right is served last and the way back starts when the
-                                // factorization ends.  A whole-block-column operation that lags the chain by `host_lag` block columns
-                                // or more goes first, oldest panel first.
-                                if (a.host_lag > 0 && o.type == ENG_OP_BIG && pd / (a.g.W / NB) - (int)(seq >> 1) >= a.host_lag)
-                                    key = ((int)(seq >> 1) << 10) | cb;
-                            }
-                        }
-                    }
-                    const unsigned long long lv = __ballot(live);
-                    if (lv != 0 && first_live == INT_MAX) first_live = base + __ffsll((long long)lv) - 1;
-                    int mk = key;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
-                    best = min(best, mk);
-                    if (a.policy == 0 && a.host_lag <= 0 && best != INT_MAX) break;   // leftmost first: nothing further right can beat it
-                }
-                if (first_live != INT_MAX) cb_lo = first_live;
-                if (best != INT_MAX) {
-                    // fetch-and-add, not compare-and-swap: with a few hundred workgroups arriving together a CAS hands out ONE unit per
-                    // round trip (the losers rescan: 384 tiles took 0.6 ms to hand out).  Whatever (sequence, unit) the add returns is
-                    // this workgroup's if the unit exists; a count past the end is nobody's (the next sequence starts from zero again).
-                    const int cb = best & 1023;
-                    unsigned long long w = 0;
-                    if (lane == 0) w = __hip_atomic_fetch_add(&st->cb[cb].claim, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w = __shfl(w, 0);
-                    accept(cb, w);
-                    continue;   // (past the end: look again)
-                }
-                // ---- deferred interchanges on the finished column blocks ---------------------------------------------------
-                if (a.g.pivot) {
-                    int bestl = INT_MAX;
-                    const int nleftcb = min(a.g.ncb, eng_first_cb(a.g, a.g.nbp));   // column blocks of the served block columns
-                    for (int base = 0; base < nleftcb; base += 64) {
-                        const int cb = base + lane;
-                        int key = INT_MAX;
-                        if (cb < nleftcb) {
-                            const unsigned long long w = eng_load(&st->cb[cb].lclaim);
-                            const unsigned lk = (unsigned)(w >> 32), u = (unsigned)w;
-                            if (lk != ENG_SEQ_DONE && eng_left_need(a.g, cb, (int)lk) <= pd && (int)u < eng_left_units<T>(a.g, cb, (int)lk)) {
-                                if (left_op_ok(cb, (int)lk)) key = ((int)lk << 10) | cb;
-                            }
-                        }
-                        int mk = key;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
-                        bestl = min(bestl, mk);
-                    }
-                    if (bestl != INT_MAX) {
-                        const int cb = bestl & 1023;
-                        unsigned long long w = 0;
-                        if (lane == 0) w = __hip_atomic_fetch_add(&st->cb[cb].lclaim, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        w = __shfl(w, 0);
-                        const unsigned lk = (unsigned)(w >> 32), u = (unsigned)w;
-                        if (lk != ENG_SEQ_DONE && (int)u < eng_left_units<T>(a.g, cb, (int)lk)) {
-                            kind = ENG_LEFT; sel_cb = cb; sel_seq = lk; sel_unit = (int)u;
-                            const long long t0 = wall_clock64();
-                            // (a later left op than the one the scan saw: its own conditions, see the scan)
-                            auto left_ok = [&]() -> bool {
-                                return leaves_done() >= eng_left_need(a.g, cb, (int)lk) && left_op_ok(cb, (int)lk);
-                            };
-                            while (!left_ok() && eng_load(&st->abort) == 0) {
-                                __builtin_amdgcn_s_sleep(16);
-                                if (wall_clock64() - t0 > 400000000LL) break;
-                            }
-                        }
-                        continue;
-                    }
-                }
-                // nothing is eligible right now: wait (one lane's worth of loads per round, not a sweep) until the critical path or
-                // the engine itself has published something since this sweep began
-                {
-                    const long long t0 = wall_clock64();
-                    bool gave_up = false;
-                    int naps = 0;
-                    for (;;) {
-                        if (eng_load(&st->epoch) != seen_epoch || eng_load(a.leaf_gate) != seen_gate ||
-                            (a.arrived && eng_load(a.arrived) != seen_arr) || eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0)
-                            break;
-                        naps = min(naps + 1, leaf_only ? 2 : 16);
-                        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(32);
-                        if (wall_clock64() - t0 > 400000000LL) { gave_up = true; break; }   // 4 s without any news: something upstream is stuck
-                    }
-                    if (a.trace && tid == 0) acct[5] += wall_clock64() - t0;
-                    if (gave_up) {
-                        if (lane == 0) {
-                            __hip_atomic_fetch_or((unsigned long long*)(a.info + 1), 17ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            eng_store(&st->abort, 1ull);
-                        }
-                        kind = ENG_EXIT;
-                        break;
-                    }
-                }
-            }
+            if (!fin) break;
+            fin_b = b + 1;
             if (lane == 0) {
-                // the acquire (an L1 invalidate) once per (column block, sequence): everything a tile of a stage reads was final when the
-                // stage was published, and the tiles other workgroups write during it are not read by this one -- the second and later
-                // tiles of the same stage keep their L1 (the U12 strip they share) and save the fence
-                const bool same_stage = kind == ENG_MAIN && (sel_seq & 1u) != 0 && sel_cb == last_cb && sel_seq == last_seq;
-                if ((kind == ENG_MAIN || kind == ENG_LEFT) && !same_stage) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                s_sel[0] = kind; s_sel[1] = sel_cb; s_sel[2] = (int)sel_seq; s_sel[3] = sel_unit;
+                const int rows = fin_b >= a.g.nbp && a.g.nbp * a.g.W >= a.g.mn ? a.g.m : min(fin_b * a.g.W, a.g.m);
+                // (the last block row takes the rows below the square part along: nothing writes them after the last panel)
+                __hip_atomic_store(a.rows_final, (unsigned long long)rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            // (all lanes of the wave: the values are wave-uniform)
-            if (kind == ENG_MAIN) { last_cb = sel_cb; last_seq = sel_seq; } else { last_cb = -1; }
         }
+    }
+    // a ticket (the value a fetch-and-add on column block cb's claim word returned): this workgroup's unit if the unit exists
+    auto accept = [&](int cb, unsigned long long w) {
+        const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
+        if (seq == ENG_SEQ_DONE) return;
+        const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+        if ((int)u >= eng_units_of(o, (int)(seq & 1u), a.g.m)) return;   // (past the end: nobody's)
+        kind = ENG_MAIN; sel_cb = cb; sel_seq = seq; sel_unit = (int)u;
+        // The scan saw an eligible sequence; the add may have landed in a LATER one (published in between).  A later
+        // stage 1 is ready by construction; a later stage 0 needs its leaves -- practically never the case (a whole
+        // sequence would have to complete between this wave's scan and its add), but then the claim is held until
+        // they are there (bounded; the leaves do not depend on this workgroup)
+        if ((seq & 1u) == 0) {
+            const long long t0 = wall_clock64();
+            const bool wl = o.type == ENG_OP_BIG && eng_big_waits_for_left(a.g, (int)(seq >> 1));
+            while ((leaves_done() < o.need ||
+                    (wl && (int)(eng_load(&st->cb[eng_first_cb(a.g, (int)(seq >> 1))].leftdone) >> 32) < eng_cbs_of_block(a.g, (int)(seq >> 1)))) &&
+                   eng_load(&st->abort) == 0) {
+                __builtin_amdgcn_s_sleep(16);
+                if (wall_clock64() - t0 > 400000000LL) break;   // (the idle timeout of the others raises the flag)
+            }
+        }
+    };
+    for (int attempt = 0; kind == ENG_NONE; ++attempt) {
+        // what this sweep is based on: if it finds nothing, the wave sleeps on these three words until one of them moves
+        const unsigned long long seen_epoch = eng_load(&st->epoch), seen_gate = eng_load(a.leaf_gate);
+        const unsigned long long seen_arr = a.arrived ? eng_load(a.arrived) : 0ull;
+        // (the three words must have been SAMPLED before anything the sweep looks at is requested: loads to different channels
+        // are served in any order, and a sweep older than the epoch it is paired with sleeps through the publication it missed.
+        // That includes the count of unfinished column blocks: read in front of the epoch, the last publication of a
+        // factorization could fall between the two reads -- the workgroup then slept on the final epoch of a finished
+        // factorization and raised the timeout flag 4 s later: one call in ~200 at N=8192, scripts/engine_stress.py)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (TRACE && lane == 0) eng_ph[6] += 1;
+        ENG_PH(0);
+        if (eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0) { kind = ENG_EXIT; break; }
+        ENG_PH(1);
+        const int pd = seen_gate > a.gate_base ? (int)(seen_gate - a.gate_base) : 0;
+        const int have = a.arrived ? (int)seen_arr : a.g.n;   // columns in place (host entry: they arrive while we run)
+        // the chain has reached its short panels: the workgroups on ITS XCD go home (one count each, the critical path waits for the sum)
+        if (may_retire && pd >= a.retire_leaf) {
+            if (lane == 0) __hip_atomic_fetch_add(&st->retired, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            kind = ENG_EXIT;
+            break;
+        }
+        // ---- main units: one lane per column block -----------------------------------------------------------------
+        int best = INT_MAX;
+        int first_live = INT_MAX;
+        for (int base = cb_lo & ~63; base < a.g.ncb; base += 64) {
+            const int cb = base + lane;
+            int key = INT_MAX;
+            bool live = false;
+            if (cb < a.g.ncb) {
+                const unsigned long long w = eng_load(&st->cb[cb].claim);
+                const unsigned seq = (unsigned)(w >> 32), u = (unsigned)w;
+                if (seq != ENG_SEQ_DONE) {
+                    live = true;
+                    const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+                    bool ok = o.need <= pd && (int)u < eng_units_of(o, (int)(seq & 1u), a.g.m) && min(a.g.n, (cb + 1) * a.g.Wc) <= have;
+                    if (leaf_only && o.type == ENG_OP_BIG) ok = false;
+                    // a block column as a whole is applied with ITS interchanges complete on all its columns (engine.hpp)
+                    if (ok && o.type == ENG_OP_BIG && (seq & 1u) == 0 && eng_big_waits_for_left(a.g, (int)(seq >> 1)))
+                        ok = (int)(eng_load(&st->cb[eng_first_cb(a.g, (int)(seq >> 1))].leftdone) >> 32) >= eng_cbs_of_block(a.g, (int)(seq >> 1));
+                    if (ok) {
+                        key = a.policy ? (((o.j0 / NB) << 10) | cb) : ((1 << 24) | cb);
+                        // host entry: a block row can leave only when the panel has reached EVERY column block; with the
+                        // leftmost-first rule alone the far right is served last and the way back starts when the
+                        // factorization ends.  A whole-block-column operation that lags the chain by `host_lag` block columns
+                        // or more goes first, oldest panel first.
+                        if (a.host_lag > 0 && o.type == ENG_OP_BIG && pd / (a.g.W / NB) - (int)(seq >> 1) >= a.host_lag)
+                            key = ((int)(seq >> 1) << 10) | cb;
+                    }
+                }
+            }
+            const unsigned long long lv = __ballot(live);
+            if (lv != 0 && first_live == INT_MAX) first_live = base + __ffsll((long long)lv) - 1;
+            int mk = key;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
+            best = min(best, mk);
+            if (a.policy == 0 && a.host_lag <= 0 && best != INT_MAX) break;   // leftmost first: nothing further right can beat it
+        }
+        if (first_live != INT_MAX) cb_lo = first_live;
+        ENG_PH(2);
+        if (best != INT_MAX) {
+            // fetch-and-add, not compare-and-swap: with a few hundred workgroups arriving together a CAS hands out ONE unit per
+            // round trip (the losers rescan: 384 tiles took 0.6 ms to hand out).  Whatever (sequence, unit) the add returns is
+            // this workgroup's if the unit exists; a count past the end is nobody's (the next sequence starts from zero again).
+            const int cb = best & 1023;
+            unsigned long long w = 0;
+            if (lane == 0) w = eng_add(&st->cb[cb].claim, 1ull);
+            w = __shfl(w, 0);
+            accept(cb, w);
+            ENG_PH(3);
+            continue;   // (past the end: look again)
+        }
+        // ---- deferred interchanges on the finished column blocks ---------------------------------------------------
+        if (a.g.pivot) {
+            int bestl = INT_MAX;
+            const int nleftcb = min(a.g.ncb, eng_first_cb(a.g, a.g.nbp));   // column blocks of the served block columns
+            for (int base = 0; base < nleftcb; base += 64) {
+                const int cb = base + lane;
+                int key = INT_MAX;
+                if (cb < nleftcb) {
+                    const unsigned long long w = eng_load(&st->cb[cb].lclaim);
+                    const unsigned lk = (unsigned)(w >> 32), u = (unsigned)w;
+                    if (lk != ENG_SEQ_DONE && eng_left_need(a.g, cb, (int)lk) <= pd && (int)u < eng_left_units<T>(a.g, cb, (int)lk)) {
+                        if (left_op_ok(cb, (int)lk)) key = ((int)lk << 10) | cb;
+                    }
+                }
+                int mk = key;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
+                bestl = min(bestl, mk);
+            }
+            ENG_PH(4);
+            if (bestl != INT_MAX) {
+                const int cb = bestl & 1023;
+                unsigned long long w = 0;
+                if (lane == 0) w = eng_add(&st->cb[cb].lclaim, 1ull);
+                w = __shfl(w, 0);
+                const unsigned lk = (unsigned)(w >> 32), u = (unsigned)w;
+                if (lk != ENG_SEQ_DONE && (int)u < eng_left_units<T>(a.g, cb, (int)lk)) {
+                    kind = ENG_LEFT; sel_cb = cb; sel_seq = lk; sel_unit = (int)u;
+                    const long long t0 = wall_clock64();
+                    // (a later left op than the one the scan saw: its own conditions, see the scan)
+                    auto left_ok = [&]() -> bool {
+                        return leaves_done() >= eng_left_need(a.g, cb, (int)lk) && left_op_ok(cb, (int)lk);
+                    };
+                    while (!left_ok() && eng_load(&st->abort) == 0) {
+                        __builtin_amdgcn_s_sleep(16);
+                        if (wall_clock64() - t0 > 400000000LL) break;
+                    }
+                }
+                continue;
+            }
+        }
+        // nothing is eligible right now: wait (one lane's worth of loads per round, not a sweep) until the critical path or
+        // the engine itself has published something since this sweep began
+        {
+            const long long t0 = wall_clock64();
+            bool gave_up = false;
+            int naps = 0;
+            for (;;) {
+                if (eng_load(&st->epoch) != seen_epoch || eng_load(a.leaf_gate) != seen_gate ||
+                    (a.arrived && eng_load(a.arrived) != seen_arr) || eng_load(&st->abort) != 0 || eng_load(&st->remaining) == 0)
+                    break;
+                naps = min(naps + 1, leaf_only ? 2 : 16);
+                for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(32);
+                if (wall_clock64() - t0 > 400000000LL) { gave_up = true; break; }   // 4 s without any news: something upstream is stuck
+            }
+            if (TRACE && lane == 0) eng_nap += wall_clock64() - t0;
+            if (TRACE) ph_t = wall_clock64();
+            if (gave_up) {
+                if (lane == 0) {
+                    __hip_atomic_fetch_or((unsigned long long*)(a.info + 1), 17ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    eng_store(&st->abort, 1ull);
+                }
+                kind = ENG_EXIT;
+                break;
+            }
+        }
+    }
+    if (lane == 0) {
+        // the acquire (an L1 invalidate) once per (column block, sequence): everything a tile of a stage reads was final when the
+        // stage was published, and the tiles other workgroups write during it are not read by this one -- the second and later
+        // tiles of the same stage keep their L1 (the U12 strip they share) and save the fence
+        const bool same_stage = kind == ENG_MAIN && (sel_seq & 1u) != 0 && sel_cb == last_cb && sel_seq == last_seq;
+        if ((kind == ENG_MAIN || kind == ENG_LEFT) && !same_stage) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        eng_sel[0] = kind; eng_sel[1] = sel_cb; eng_sel[2] = (int)sel_seq; eng_sel[3] = sel_unit;
+    }
+    ENG_PH(5);
+    if (lane == 0) {   // (wave 0's state between two scans)
+        eng_wst[0] = cb_lo; eng_wst[1] = fin_b;
+        eng_wst[2] = kind == ENG_MAIN ? sel_cb : -1; eng_wst[3] = (int)sel_seq;
+    }
+}
+
+// ---- a unit is finished: count it, and if it was the last of its stage, publish the next one.  One lane; a function of its own for the same
+// reason as the scan (the path from the end of a stage's last unit to the publication of the next stage is what every column block's sequence
+// is made of)
+template <typename T, bool TRACE>
+__device__ __attribute__((noinline)) void eng_complete(unsigned long long kernarg, int kind, int cb, unsigned seq, int unit)
+{
+    const unsigned long long ku = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(kernarg >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)kernarg);
+    EngArgs<T> a;
+    {
+        const __attribute__((address_space(4))) unsigned* kp = (const __attribute__((address_space(4))) unsigned*)ku;
+        unsigned* ad = reinterpret_cast<unsigned*>(&a);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(EngArgs<T>) / 4); ++i) ad[i] = kp[i];
+    }
+    EngState* const st = a.st;
+    kind = __builtin_amdgcn_readfirstlane(kind); cb = __builtin_amdgcn_readfirstlane(cb);
+    seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq); unit = __builtin_amdgcn_readfirstlane(unit);
+    // a Schur tile stored write-through has nothing left in this XCD's L2 (its stores are acknowledged: s_waitcnt above)
+    if (!(a.write_through && kind == ENG_MAIN && (seq & 1u) != 0)) eng_release();
+    EngCB* c = &st->cb[cb];
+    if (kind == ENG_MAIN) {
+        const int units = eng_units(a, cb, seq);
+        // done = finished units (low word) | finished units of a leaf window's FIRST tile column (high word)
+        const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
+        const int tiles_m = (a.g.m - (o.j0 + o.jb) + G_BM - 1) / G_BM;
+        const bool first_col = (seq & 1u) != 0 && o.type == ENG_OP_LEAF && unit < tiles_m;
+        const unsigned long long dd = eng_add(&c->done, 1ull + (first_col ? 1ull << 32 : 0ull)) +
+                                      1ull + (first_col ? 1ull << 32 : 0ull);
+        const unsigned long long d = dd & 0xffffffffull;
+        // Publications carry no release fence (round 6: each used to start with an ACQ_REL fence and publish through four RELEASE
+        // atomics -- an L2 write-back of this XCD in front of every one of them, on the path every stage of every column block's
+        // sequence goes through).  None is needed: whatever a unit wrote is at the memory side BEFORE its count (tiles are stored
+        // write-through and acknowledged, strips are released by their own workgroup), the workgroup that sees the last count only
+        // announces it, and the consumers take their units with an acquire (same box, alternating: N=12288 through the engine 45.2 -> 44.0
+        // ms, Float32 N=16384 55.3 -> 54.9, Float64 N=16384 unchanged).  What has to hold is the ORDER of the publisher's own words:
+        // the counter reads zero before the next sequence can be counted, and the epoch moves after everything it announces.
+        if (first_col && (int)(dd >> 32) == tiles_m && (int)d != units) {
+            // the window's first tile column is complete: the critical path may go on (prog = 2 * completed ops + 1).  A maximum, not a
+            // store: the workgroup that completes the whole sequence may publish 2 * (op + 1) BEFORE this one, delayed between its
+            // count and this line, gets here -- a plain store would take the word back to 2 * op + 1 for good
+            eng_max(&c->prog, 2ull * (unsigned long long)(seq >> 1) + 1ull);
+        }
+        if ((int)d == units) {
+            if (TRACE && o.type == ENG_OP_LEAF && cb == (o.j0 + o.jb + NB) / a.g.Wc)
+                a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
+            if (TRACE && o.type == ENG_OP_LEAF && cb == eng_first_cb(a.g, o.j0 / a.g.W + 1) && o.j0 / NB < 2048)
+                a.trace[(2048 + o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
+            eng_store(&c->done, 0ull);
+            const unsigned end = 2u * (unsigned)eng_nops(a.g, cb);
+            unsigned ns = seq + 1;
+            while (ns < end && eng_units(a, cb, ns) == 0) ++ns;   // (an operation with no columns left, a panel with no rows below it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((ns >> 1) != (seq >> 1)) {
+                for (unsigned k = seq >> 1; k < (ns >> 1); ++k)   // (the operations just completed, skipped ones included)
+                    if ((int)k < eng_nbig(a.g, cb))
+                        eng_add(&st->cb[eng_first_cb(a.g, (int)k)].bigdone, 1ull);
+                eng_max(&c->prog, 2ull * (unsigned long long)(ns >> 1));
+            }
+            if (ns >= end) {
+                eng_store(&c->claim, (unsigned long long)ENG_SEQ_DONE << 32);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (whoever reads remaining == 0 finds every claim word closed)
+                eng_add(&st->remaining, ~0ull);
+            } else {
+                eng_store(&c->claim, (unsigned long long)ns << 32);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            eng_add(&st->epoch, 1ull);
+        }
+    } else {
+        const int units = eng_left_units<T>(a.g, cb, (int)seq);
+        const unsigned long long d = eng_add(&c->ldone, 1ull) + 1;
+        if ((int)d == units) {
+            eng_store(&c->ldone, 0ull);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int nleft = eng_nleft(a.g, cb);
+            int nk = (int)seq + 1;
+            while (nk < nleft && eng_left_units<T>(a.g, cb, nk) == 0) ++nk;
+            const int pbl = eng_pb(a.g, cb);
+            for (int k = (int)seq; k < nk; ++k)   // the left ops just completed (k = 0: this block column's own interchanges; k >= 1:
+                eng_add(&st->cb[eng_first_cb(a.g, pbl + k)].leftdone, k == 0 ? 1ull << 32 : 1ull);   // block column pbl + k has reached it)
+            eng_store(&c->lprog, (unsigned long long)nk);
+            if (nk >= nleft) {
+                eng_store(&c->lclaim, (unsigned long long)ENG_SEQ_DONE << 32);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                eng_add(&st->remaining, ~0ull);
+            } else {
+                eng_store(&c->lclaim, (unsigned long long)nk << 32);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            eng_add(&st->epoch, 1ull);
+        }
+    }
+}
+
+template <typename T, bool TRACE>
+__global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char eng_smem_raw[];
+    T* smem = reinterpret_cast<T*>(eng_smem_raw);
+    const EngUnit<T> ua = eng_unit_args<T>(a, smem);
+    EngState* const st = a.st;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        unsigned my_xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+        eng_add(&st->xcc_wgs[my_xcc & 7u], 1ull);
+        eng_wst[0] = 0; eng_wst[1] = 0; eng_wst[2] = -1; eng_wst[3] = 0;
+        eng_nap = 0;
+        for (int k = 0; k < 8; ++k) eng_ph[k] = 0;
+    }
+
+    // measurement (RFLU_ENGINE_TRACE, the TRACE instantiation): where a workgroup's time goes -- [0] whole-block-column tiles, [1] leaf-window tiles,
+    // [2] strips + solves, [3] deferred interchanges, [4] everything between two units (scan, claim, waiting, completion), [5] of [4] the part spent
+    // asleep with nothing eligible, [6] of [4] from the end of a unit to its count / publication being out; summed over the workgroups
+    long long acct[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long acct_t = TRACE ? wall_clock64() : 0;
+    for (;;) {
+        if (tid < 64) eng_scan<T, TRACE>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
         __syncthreads();
-        const int kind = s_sel[0], cb = s_sel[1], unit = s_sel[3];
-        const unsigned seq = (unsigned)s_sel[2];
-        if (a.trace && tid == 0) { const long long t = wall_clock64(); acct[4] += t - acct_t; acct_t = t; }
+        const int kind = eng_sel[0], cb = eng_sel[1], unit = eng_sel[3];
+        const unsigned seq = (unsigned)eng_sel[2];
+        if (TRACE && tid == 0) { const long long t = wall_clock64(); acct[4] += t - acct_t; acct_t = t; }
         if (kind == ENG_EXIT) break;
         int acct_k = 3;
         if (kind == ENG_MAIN) {
             const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
             acct_k = (seq & 1u) == 0 ? 2 : (o.type == ENG_OP_BIG ? 0 : 1);
-            if (a.trace && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == (o.j0 + o.jb + NB) / a.g.Wc)
+            if (TRACE && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == (o.j0 + o.jb + NB) / a.g.Wc)
                 a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 2 : 0)] = wall_clock64();
             // (second set, leaves < 2048: the same leaf on the first column block of the NEXT block column)
-            if (a.trace && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == eng_first_cb(a.g, o.j0 / a.g.W + 1) && o.j0 / NB < 2048)
+            if (TRACE && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == eng_first_cb(a.g, o.j0 / a.g.W + 1) && o.j0 / NB < 2048)
                 a.trace[(2048 + o.j0 / NB) * 4 + ((seq & 1u) ? 2 : 0)] = wall_clock64();
             if ((seq & 1u) == 0) eng_prep_unit<T>(ua, o, unit);
             else eng_gemm_unit<T>(ua, o, unit);
@@ -684,91 +841,17 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
         }
         // ---- completion: drain every wave's stores, one lane releases and counts ------------------------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (a.trace && tid == 0) { const long long t = wall_clock64(); acct[acct_k] += t - acct_t; acct_t = t; }
+        if (TRACE && tid == 0) { const long long t = wall_clock64(); acct[acct_k] += t - acct_t; acct_t = t; }
         __syncthreads();
-        if (tid == 0) {
-            // a Schur tile stored write-through has nothing left in this XCD's L2 (its stores are acknowledged: s_waitcnt above)
-            if (!(a.write_through && kind == ENG_MAIN && (seq & 1u) != 0)) eng_release();
-            EngCB* c = &st->cb[cb];
-            if (kind == ENG_MAIN) {
-                const int units = eng_units(a, cb, seq);
-                // done = finished units (low word) | finished units of a leaf window's FIRST tile column (high word)
-                const EngOp o = eng_op(a.g, cb, (int)(seq >> 1));
-                const int tiles_m = (a.g.m - (o.j0 + o.jb) + G_BM - 1) / G_BM;
-                const bool first_col = (seq & 1u) != 0 && o.type == ENG_OP_LEAF && unit < tiles_m;
-                const unsigned long long dd = __hip_atomic_fetch_add(&c->done, 1ull + (first_col ? 1ull << 32 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
-                                              1ull + (first_col ? 1ull << 32 : 0ull);
-                const unsigned long long d = dd & 0xffffffffull;
-                // Publications carry no release fence (round 6: each used to start with an ACQ_REL fence and publish through four RELEASE
-                // atomics -- an L2 write-back of this XCD in front of every one of them, on the path every stage of every column block's
-                // sequence goes through).  None is needed: whatever a unit wrote is at the memory side BEFORE its count (tiles are stored
-                // write-through and acknowledged, strips are released by their own workgroup), the workgroup that sees the last count only
-                // announces it, and the consumers take their units with an acquire (same box, alternating: N=12288 through the engine 45.2 -> 44.0
-                // ms, Float32 N=16384 55.3 -> 54.9, Float64 N=16384 unchanged).  What has to hold is the ORDER of the publisher's own words:
-                // the counter reads zero before the next sequence can be counted, and the epoch moves after everything it announces.
-                if (first_col && (int)(dd >> 32) == tiles_m && (int)d != units) {
-                    // the window's first tile column is complete: the critical path may go on (prog = 2 * completed ops + 1).  A maximum, not a
-                    // store: the workgroup that completes the whole sequence may publish 2 * (op + 1) BEFORE this one, delayed between its
-                    // count and this line, gets here -- a plain store would take the word back to 2 * op + 1 for good
-                    __hip_atomic_fetch_max(&c->prog, 2ull * (unsigned long long)(seq >> 1) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if ((int)d == units) {
-                    if (a.trace && o.type == ENG_OP_LEAF && cb == (o.j0 + o.jb + NB) / a.g.Wc)
-                        a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
-                    if (a.trace && o.type == ENG_OP_LEAF && cb == eng_first_cb(a.g, o.j0 / a.g.W + 1) && o.j0 / NB < 2048)
-                        a.trace[(2048 + o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
-                    eng_store(&c->done, 0ull);
-                    const unsigned end = 2u * (unsigned)eng_nops(a.g, cb);
-                    unsigned ns = seq + 1;
-                    while (ns < end && eng_units(a, cb, ns) == 0) ++ns;   // (an operation with no columns left, a panel with no rows below it)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if ((ns >> 1) != (seq >> 1)) {
-                        for (unsigned k = seq >> 1; k < (ns >> 1); ++k)   // (the operations just completed, skipped ones included)
-                            if ((int)k < eng_nbig(a.g, cb))
-                                __hip_atomic_fetch_add(&st->cb[eng_first_cb(a.g, (int)k)].bigdone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_max(&c->prog, 2ull * (unsigned long long)(ns >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (ns >= end) {
-                        eng_store(&c->claim, (unsigned long long)ENG_SEQ_DONE << 32);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (whoever reads remaining == 0 finds every claim word closed)
-                        __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        eng_store(&c->claim, (unsigned long long)ns << 32);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(&st->epoch, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else {
-                const int units = eng_left_units<T>(a.g, cb, (int)seq);
-                const unsigned long long d = __hip_atomic_fetch_add(&c->ldone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-                if ((int)d == units) {
-                    eng_store(&c->ldone, 0ull);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const int nleft = eng_nleft(a.g, cb);
-                    int nk = (int)seq + 1;
-                    while (nk < nleft && eng_left_units<T>(a.g, cb, nk) == 0) ++nk;
-                    const int pbl = eng_pb(a.g, cb);
-                    for (int k = (int)seq; k < nk; ++k)   // the left ops just completed (k = 0: this block column's own interchanges; k >= 1:
-                        __hip_atomic_fetch_add(&st->cb[eng_first_cb(a.g, pbl + k)].leftdone, k == 0 ? 1ull << 32 : 1ull,   // block column pbl + k has reached it)
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    eng_store(&c->lprog, (unsigned long long)nk);
-                    if (nk >= nleft) {
-                        eng_store(&c->lclaim, (unsigned long long)ENG_SEQ_DONE << 32);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __hip_atomic_fetch_add(&st->remaining, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        eng_store(&c->lclaim, (unsigned long long)nk << 32);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(&st->epoch, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        if (a.trace && tid == 0) acct[6] += wall_clock64() - acct_t;
+        if (tid == 0) eng_complete<T, TRACE>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr(), kind, cb, seq, unit);
+        if (TRACE && tid == 0) acct[6] += wall_clock64() - acct_t;
         __syncthreads();
     }
-    if (a.trace && tid == 0)
-        for (int k = 0; k < 7; ++k) __hip_atomic_fetch_add((unsigned long long*)&a.trace[4096 * 4 + k], (unsigned long long)acct[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (TRACE && tid == 0) {
+        acct[5] = eng_nap;
+        for (int k = 0; k < 7; ++k) eng_add((unsigned long long*)&a.trace[4096 * 4 + k], (unsigned long long)acct[k]);
+        for (int k = 0; k < 8; ++k) eng_add((unsigned long long*)&a.trace[4096 * 4 + 8 + k], (unsigned long long)eng_ph[k]);
+    }
 }
 
 size_t engine_lds_bytes(size_t esize)
@@ -781,11 +864,17 @@ int launch_engine(Handle* h, hipStream_t stream, const EngArgs<T>& a, int wgs)
 {
     const size_t lds = engine_lds_bytes(sizeof(T));
     bool& attr_set = h->eng_attr_set[sizeof(T) == 8 ? 0 : 1];
+    if (a.trace) {   // the accounting instantiation (RFLU_ENGINE_TRACE): the shipped one carries neither its counters nor their code
+        RFLU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&engine_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((engine_kernel<T, true>), dim3((unsigned)wgs), dim3(256), lds, stream, a);
+        RFLU_HIP(hipGetLastError());
+        return RFLU_OK;
+    }
     if (!attr_set) {
-        RFLU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&engine_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RFLU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&engine_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((engine_kernel<T>), dim3((unsigned)wgs), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((engine_kernel<T, false>), dim3((unsigned)wgs), dim3(256), lds, stream, a);
     RFLU_HIP(hipGetLastError());
     return RFLU_OK;
 }

@@ -421,7 +421,7 @@ def main():
                                         "after the light phases (DESIGN.md section 7); sum of flops / sum of launch durations")
             if through_engine:
                 # the shipped schedule of this size runs its updates in ONE resident kernel (csrc/engine.hip: the persistent update engine,
-                # default for pivoted matrices of more than 12288 columns): that launch is the dominant kernel
+                # default for pivoted matrices of more than 11264 columns): that launch is the dominant kernel
                 roof["kernel"] = ("engine_kernel (persistent update engine: interchanges, block-row solves and every Schur tile "
                                   "C -= A*B of the factorization, pulled from per-column-block counters; the tile code is gemm_sub_kernel's)")
                 roof["note_in_schedule"] = ("ONE launch: the engine is resident on 224 of 256 CUs for the whole factorization.  flops = the "

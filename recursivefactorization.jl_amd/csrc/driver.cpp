@@ -373,7 +373,9 @@ static int gemm_public(Handle* h, int64_t M, int64_t N, int64_t K, const T* A, i
 // measured on MI355X (bench.py --blocksize sweep): the knee moves right with the matrix size
 static int64_t default_blocksize(int64_t mn)
 {
-    return mn < 1024 ? -1 : (mn <= 12288 ? 256 : (mn <= 16384 ? 512 : (mn <= 24576 ? 1024 : 2048)));
+    // (512 from 11265 columns on: where the update engine, which wants 512-wide block columns, starts to win -- N=11264 38.4 vs 38.6 ms at 256
+    // through the streams, N=12288 41.5 vs 43.5, N=10240 33.8 vs 32.9: round 6)
+    return mn < 1024 ? -1 : (mn <= 11264 ? 256 : (mn <= 16384 ? 512 : (mn <= 24576 ? 1024 : 2048)));
 }
 
 template <typename T>
@@ -1129,6 +1131,18 @@ static int factor_leafwise(Fact<T>& f, int64_t W, int64_t b_begin, hipStream_t U
                         fprintf(stderr, " || next block column: first claim at %.3f ms (%.1f us after the previous leaf's window there was complete) | stage 0 %.1f | to first tile %.1f | tiles %.1f",
                                 (n4[0] - hs[0]) / 1e5, (n4[0] - n4[-1]) / 100.0, (n4[1] - n4[0]) / 100.0, (n4[2] - n4[1]) / 100.0, (n4[3] - n4[2]) / 100.0);
                     fprintf(stderr, "\n");
+                    // behind the last leaf of a block column b: what stands between it and BIG(b) being complete on the column block the chain needs next
+                    const int LPBt = (int)(W / NB);
+                    if ((g + 1) % LPBt == 0 && g / LPBt < 512) {
+                        const int b = g / LPBt;
+                        const long long* bg = hs.data() + (size_t)(1024 + b) * 4;
+                        const long long* lf = hs.data() + (size_t)(1536 + b) * 4;
+                        const long long t0 = n4[0];   // LEAF(last leaf of b) first claimed on the next block column: the leaf has just been factored
+                        if (t0 && bg[0] && bg[3])
+                            fprintf(stderr, "   block column %d ends (its last leaf's window is claimed at +0): own deferred interchanges +%.0f .. +%.0f us | BIG(%d) on the first column block of block column %d: "
+                                            "stage 0 +%.0f .. +%.0f | tiles +%.0f .. +%.0f us\n",
+                                    b, (lf[0] - t0) / 100.0, (lf[1] - t0) / 100.0, b, b + 2, (bg[0] - t0) / 100.0, (bg[1] - t0) / 100.0, (bg[2] - t0) / 100.0, (bg[3] - t0) / 100.0);
+                    }
                 }
             }
             RFLU_HIP(hipMemsetAsync(eng_trace_buf, 0, (4096 * 4 + 16) * sizeof(long long), P));
@@ -1438,13 +1452,13 @@ static int getrf_rm(Handle* h, int64_t m, int64_t n, T* R, int64_t ld, int64_t* 
             // column 0, its side / update streams replaced by the engine); below that the streams and the XCD-local leaves take over
             int64_t eng_end = 0;
             // the engine where asked for (RFLU_ENGINE=1, the host entry) or, by default, where it measures faster than the streams: with
-            // pivoting at the default block width of 512, i.e. more than 12288 columns (N=16384 Float64: 72 vs 75 ms, Float32 -- round 6 --
-            // 56.0 vs 58.8; NoPivot: 68.9 vs 64.1, the streams stay; at 256-wide block columns the streams win: N=12288 44.7 vs 43.7, N=8192
-            // 25.7 vs 24.0).  A Float32 pivot search may answer another summation order with another (equally valid) pivot sequence from a
+            // pivoting at the default block width of 512, i.e. more than 11264 columns (N=16384 Float64: 71.5 vs 75 ms, Float32 -- round 6 --
+            // 55.3 vs 58.8; N=12288: 41.5 vs 43.5 through the streams at 256, Float32 36.9 vs 38.4; NoPivot at N=16384: 68.9 vs 64.1, the
+            // streams stay; below, at 256-wide block columns, the streams win: N=10240 32.9 vs 33.8, N=8192 24.0 vs 24.9).  A Float32 pivot search may answer another summation order with another (equally valid) pivot sequence from a
             // near-tie on -- between the stream schedules too: tests hold Float32 to the residual and a floor of equal
             // leading pivots, not to the bits of another schedule.
             const bool eng_wanted = h->eng_host_mode || h->tune.engine == 1 || h->tune.engine_replay ||
-                                    (h->tune.engine < 0 && pivot && default_bs && Wb == 512 && mn > 12288 && m >= n);
+                                    (h->tune.engine < 0 && pivot && default_bs && Wb == 512 && mn > 11264 && m >= n);
             if (eng_wanted && leafwise && Wb >= 2 * NB && Wb <= 512 && W_wide == 0 && m <= 32 * (int64_t)PANEL_THREADS && engine_usable<T>(h, f, Wb)) {
                 const int64_t er = h->eng_host_mode ? 0 : std::max<int64_t>(h->tune.engine_rows, 0);   // (host entry: every block column through the engine)
                 eng_end = m <= er ? 0 : std::min(nblk, (m - er + Wb - 1) / Wb);

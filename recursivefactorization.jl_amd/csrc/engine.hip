@@ -475,20 +475,24 @@ __device__ __attribute__((noinline)) void eng_scan(unsigned long long kernarg)
 
     // every LEAF op of the block column pb is complete: on its own column blocks (they have nothing else left) and on those of the
     // `ahead` block columns to its right
-    auto leaf_ops_complete = [&](int pb) -> bool {
+    // (`but_last`: every LEAF op but those of the block column's LAST leaf -- what the block column's own deferred interchanges wait for: they
+    // move rows in the columns of the earlier leaves, which the last leaf's windows do not read, and with that they, and BIG(pb) on the column
+    // block the chain needs next, start one leaf window earlier: the window of the last leaf on the block columns to the right)
+    auto leaf_ops_complete = [&](int pb, bool but_last) -> bool {
         const int c0 = eng_first_cb(a.g, pb), n0 = eng_cbs_of_block(a.g, pb);
         for (int c = c0; c < c0 + n0; ++c)
-            if ((unsigned)(eng_load(&st->cb[c].claim) >> 32) != ENG_SEQ_DONE) return false;
+            if ((unsigned)(eng_load(&st->cb[c].claim) >> 32) != ENG_SEQ_DONE) return false;   // (the own column blocks have no LEAF op of the last leaf)
+        const int skip = but_last && eng_leaves_of_block(a.g, pb) > 1 ? 1 : 0;
         for (int q = pb + 1; q <= pb + eng_ahead(a.g); ++q) {
             const int c1 = eng_first_cb(a.g, q), n1 = eng_cbs_of_block(a.g, q);
             for (int c = c1; c < c1 + n1; ++c)
-                if ((int)eng_load(&st->cb[c].prog) < 2 * eng_ops_through_block(a.g, c, pb)) return false;
+                if ((int)eng_load(&st->cb[c].prog) < 2 * (eng_ops_through_block(a.g, c, pb) - skip)) return false;
         }
         return true;
     };
     auto left_op_ok = [&](int cb, int lk) -> bool {
         const int pb = eng_pb(a.g, cb);
-        if (lk == 0) return leaf_ops_complete(pb);
+        if (lk == 0) return leaf_ops_complete(pb, true);
         return (int)eng_load(&st->cb[eng_first_cb(a.g, pb)].bigdone) >= eng_big_users(a.g, pb);   // nobody reads this block column's L any more
     };
     auto leaves_done = [&]() -> int {
@@ -509,7 +513,7 @@ __device__ __attribute__((noinline)) void eng_scan(unsigned long long kernarg)
             const int b = fin_b;
             if (b >= a.g.nbp) break;
             const int fb = eng_first_cb(a.g, b);
-            bool fin = leaves_done() >= b * (a.g.W / NB) + eng_leaves_of_block(a.g, b) && leaf_ops_complete(b) &&
+            bool fin = leaves_done() >= b * (a.g.W / NB) + eng_leaves_of_block(a.g, b) && leaf_ops_complete(b, false) &&
                        (int)eng_load(&st->cb[fb].bigdone) >= eng_big_users(a.g, b);
             if (fin && a.g.pivot) {
                 const unsigned long long ld = eng_load(&st->cb[fb].leftdone);
@@ -749,6 +753,8 @@ __device__ __attribute__((noinline)) void eng_complete(unsigned long long kernar
                 a.trace[(o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
             if (TRACE && o.type == ENG_OP_LEAF && cb == eng_first_cb(a.g, o.j0 / a.g.W + 1) && o.j0 / NB < 2048)
                 a.trace[(2048 + o.j0 / NB) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
+            if (TRACE && o.type == ENG_OP_BIG && cb == eng_first_cb(a.g, o.j0 / a.g.W + eng_ahead(a.g) + 1) && o.j0 / a.g.W < 512)
+                a.trace[(1024 + o.j0 / a.g.W) * 4 + ((seq & 1u) ? 3 : 1)] = wall_clock64();
             eng_store(&c->done, 0ull);
             const unsigned end = 2u * (unsigned)eng_nops(a.g, cb);
             unsigned ns = seq + 1;
@@ -774,6 +780,8 @@ __device__ __attribute__((noinline)) void eng_complete(unsigned long long kernar
         const int units = eng_left_units<T>(a.g, cb, (int)seq);
         const unsigned long long d = eng_add(&c->ldone, 1ull) + 1;
         if ((int)d == units) {
+            if (TRACE && seq == 0 && cb == eng_first_cb(a.g, eng_pb(a.g, cb)) && eng_pb(a.g, cb) < 512)
+                a.trace[(1536 + eng_pb(a.g, cb)) * 4 + 1] = wall_clock64();
             eng_store(&c->ldone, 0ull);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int nleft = eng_nleft(a.g, cb);
@@ -834,9 +842,15 @@ __global__ void __launch_bounds__(256, 2) engine_kernel(EngArgs<T> a)
             // (second set, leaves < 2048: the same leaf on the first column block of the NEXT block column)
             if (TRACE && tid == 0 && o.type == ENG_OP_LEAF && unit == 0 && cb == eng_first_cb(a.g, o.j0 / a.g.W + 1) && o.j0 / NB < 2048)
                 a.trace[(2048 + o.j0 / NB) * 4 + ((seq & 1u) ? 2 : 0)] = wall_clock64();
+            // (third set: BIG(b) on the column block the chain needs next, the first one of block column b + ahead + 1: slots (1024 + b) * 4 ..)
+            if (TRACE && tid == 0 && o.type == ENG_OP_BIG && unit == 0 && cb == eng_first_cb(a.g, o.j0 / a.g.W + eng_ahead(a.g) + 1) && o.j0 / a.g.W < 512)
+                a.trace[(1024 + o.j0 / a.g.W) * 4 + ((seq & 1u) ? 2 : 0)] = wall_clock64();
             if ((seq & 1u) == 0) eng_prep_unit<T>(ua, o, unit);
             else eng_gemm_unit<T>(ua, o, unit);
         } else {
+            // (fourth set: the block column's own deferred interchanges, left op 0 on its first column block: slots (1536 + b) * 4 + {0, 1})
+            if (TRACE && tid == 0 && seq == 0 && unit == 0 && cb == eng_first_cb(a.g, eng_pb(a.g, cb)) && eng_pb(a.g, cb) < 512)
+                a.trace[(1536 + eng_pb(a.g, cb)) * 4] = wall_clock64();
             eng_left_unit<T>(ua, cb, (int)seq, unit);
         }
         // ---- completion: drain every wave's stores, one lane releases and counts ------------------------------------------------

@@ -1,5 +1,5 @@
-"""-m gpu: the persistent update engine (csrc/engine.hip; RFLU_ENGINE=1 here -- by default it serves Float64 pivoted matrices of more than 12288
-columns and the host entry: DESIGN.md section 3.12).  Every trailing update of the block columns with tall panels is pulled by resident workgroups from per-column-block
+"""-m gpu: the persistent update engine (csrc/engine.hip; RFLU_ENGINE=1 here -- by default it serves pivoted matrices of more than 11264
+columns and the host entry: DESIGN.md section 3.5).  Every trailing update of the block columns with tall panels is pulled by resident workgroups from per-column-block
 counters instead of being enqueued on the side / update streams; the eliminations and their order per column are those of the
 stream schedules (src/lu.jl:189-263, :265-284), so pivots must be identical and factors equal to rounding."""
 import numpy as np
@@ -79,9 +79,9 @@ def test_engine_without_retirement(monkeypatch):
     assert matvec_residual(A, G.factors, G.ipiv) < 1e-12
 
 
-@pytest.mark.parametrize("m,n", [(13000, 13000), (16384, 12800), (16000, 15000)])
+@pytest.mark.parametrize("m,n", [(12288, 12288), (12000, 11500), (13000, 13000), (16384, 12800), (16000, 15000)])
 def test_default_rule_sends_these_shapes_through_the_engine(m, n, monkeypatch):
-    """RFLU_ENGINE unset: Float64 pivoted matrices of more than 12288 columns (default block width, at most 16384 rows, not fat) are
+    """RFLU_ENGINE unset: pivoted matrices of more than 11264 columns (default block width, at most 16384 rows, not fat) are
     factored through the engine; pivots equal to the stream schedule's (RFLU_ENGINE=0), factors equal to rounding."""
     monkeypatch.setenv("RFLU_ENGINE", "0")
     A, F = _factor(n, np.float64, True, 0, m=m)
@@ -127,7 +127,7 @@ def test_engine_against_the_cpu_oracle(m, n, bs, monkeypatch):
 
 
 def test_default_rule_float32_headline_size_goes_through_the_engine(monkeypatch):
-    """Round 6: Float32 pivoted matrices of more than 12288 columns take the engine by default too (N=16384: 56.0 vs 58.8 ms).  Float32 is held
+    """Round 6: Float32 pivoted matrices of more than 11264 columns take the engine by default too (N=16384: 55.3 vs 58.8 ms).  Float32 is held
     to what the reference holds it to -- info, the residual bound (test/runtests.jl:19-20) -- plus a floor of leading pivots equal to the
     stream schedule's: past a near-tie two valid summation orders may choose different pivots."""
     n = 16384

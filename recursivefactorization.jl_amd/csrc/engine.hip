@@ -124,11 +124,19 @@ __device__ __attribute__((noinline)) void eng_prep_unit(const EngUnit<T> a, cons
     typedef typename Mfma<T>::acc_t acc_t;
     constexpr int VW = 16 / (int)sizeof(T);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j0 = o.j0, jb = o.jb;
-    const int c0 = o.c_lo + u * EP_COLS;
-    const int nc = min(EP_COLS, o.nc - u * EP_COLS);
-    T* const R = (T*)a.R;
-    const int64_t ld = a.ld;
+    // (function arguments arrive in vector registers; what is the same in every lane is made scalar again for Float64: the block-row solve below
+    // holds its block row in 128 VGPRs and has none to spare for copies of a pitch or a base address -- it reloaded them from scratch some ten times
+    // per 64-row step: N=16384 71.5 -> 70.3 ms; Float32 has the registers and measured no faster)
+    constexpr bool UNI = sizeof(T) == 8;
+    auto uni = [](int v) { return UNI ? __builtin_amdgcn_readfirstlane(v) : v; };
+    auto uni64 = [](unsigned long long v) {
+        return UNI ? ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v) : v;
+    };
+    const int j0 = uni(o.j0), jb = uni(o.jb);
+    const int c0 = uni(o.c_lo + u * EP_COLS);
+    const int nc = uni(min(EP_COLS, o.nc - u * EP_COLS));
+    T* const R = (T*)uni64((unsigned long long)(T*)a.R);
+    const int64_t ld = (int64_t)uni64((unsigned long long)a.ld);
     const int* const pm_cnt = (const int*)a.pm_cnt;
     const int* const pm_dst = (const int*)a.pm_dst;
     const int* const pm_src = (const int*)a.pm_src;
@@ -145,7 +153,7 @@ __device__ __attribute__((noinline)) void eng_prep_unit(const EngUnit<T> a, cons
         __syncthreads();   // (every chunk of laswp_strip ends with s_waitcnt vmcnt(0): the rows are in place)
     }
     const T* L = R + (int64_t)j0 * ld + j0;
-    const T* Linv = (const T*)a.linv + (int64_t)(j0 / NB) * NB * NB;
+    const T* Linv = (const T*)uni64((unsigned long long)(const T*)a.linv) + (int64_t)(j0 / NB) * NB * NB;
     T* B = R + (int64_t)j0 * ld + c0;
     const int nblk = (jb + NB - 1) / NB;
     const int fi = lane & 15, fk = lane >> 4;
@@ -352,24 +360,33 @@ __device__ __attribute__((noinline)) void eng_gemm_unit(const EngUnit<T> a, cons
 {
     constexpr int VW = 16 / (int)sizeof(T);
     T* const smem = (T*)a.smem;
-    T* const Rg = (T*)a.R;
-    const int je = o.j0 + o.jb;
+    // (what is the same in every lane made scalar again, as in eng_prep_unit: the tile code then computes its addresses and loop conditions on
+    // the scalar unit, as it does inside gemm_sub_kernel, whose arguments are kernel arguments)
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni64 = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    T* const Rg = (T*)uni64((unsigned long long)(T*)a.R);
+    const int64_t ld = (int64_t)uni64((unsigned long long)a.ld);
+    const int oj0 = uni(o.j0), ojb = uni(o.jb), oclo = uni(o.c_lo);
+    t = uni(t);
+    const int je = oj0 + ojb;
     GemmArgs<T> g;
-    g.M = a.g.m - je;
-    g.N = o.nc;
-    g.K = o.jb;
-    g.A = Rg + (int64_t)je * a.ld + o.j0;
-    g.B = Rg + (int64_t)o.j0 * a.ld + o.c_lo;
-    g.C = Rg + (int64_t)je * a.ld + o.c_lo;
-    g.lda = g.ldb = g.ldc = a.ld;
+    g.M = uni(a.g.m) - je;
+    g.N = uni(o.nc);
+    g.K = ojb;
+    g.A = Rg + (int64_t)je * ld + oj0;
+    g.B = Rg + (int64_t)oj0 * ld + oclo;
+    g.C = Rg + (int64_t)je * ld + oclo;
+    g.lda = g.ldb = g.ldc = ld;
     g.tiles_m = (g.M + G_BM - 1) / G_BM;
     g.tiles_n = (g.N + G_BN - 1) / G_BN;
-    g.vec_ok = (reinterpret_cast<uintptr_t>(Rg) % 16 == 0) && (a.ld % VW == 0) && (o.c_lo % VW == 0) && (o.j0 % VW == 0);
-    g.flags = a.gemm_flags | (a.write_through ? 4 : 0);   // write-through C stores, no release fence behind a tile
+    g.vec_ok = (reinterpret_cast<uintptr_t>(Rg) % 16 == 0) && (ld % VW == 0) && (oclo % VW == 0) && (oj0 % VW == 0);
+    g.flags = uni(a.gemm_flags | (a.write_through ? 4 : 0));   // write-through C stores, no release fence behind a tile
     g.na_tiles_n = 0; g.sig_flag = nullptr; g.sig_val = 0; g.sig_cnt = nullptr;
     // G_GROUP_M tile rows are walked together, column after column: consecutive claims share the B panel, then the A panels
     int tile_m, tile_n;
-    if (o.type == ENG_OP_LEAF) {
+    if (uni(o.type) == ENG_OP_LEAF) {
         // a leaf's window, first tile column first: the critical-path stream waits for exactly those columns (the next leaf's
         // lookahead strip is the leftmost of the window) and is told when they are complete, not when the whole window is
         tile_n = t / g.tiles_m;

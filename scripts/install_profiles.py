@@ -68,9 +68,11 @@ if os.path.exists(os.path.join(G, d16, "engine_pmc.txt")):
         + "".join(l for l in open(os.path.join(G, d16, "engine_replay.txt")) if "amdgpu.ids" not in l))
 if os.path.exists(os.path.join(G, rnd, "engine_trace.txt")):
     open(os.path.join(P, f"{tag}_engine_workgroup_time.txt"), "w").write(
-        f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}) -- RFLU_ENGINE_TRACE=36:8 python scripts/time_env.py 16384 3: the accounting the engine keeps of its\n"
-        "# 448 workgroups' time by kind of unit (100 MHz clock, summed over the workgroups), and for the leaves 36..43 (block column 4) when LEAF(g) was first claimed on the\n"
-        "# column block of its first columns and -- behind `||` -- on the NEXT block column's first column block: the catch-up behind BIG(b - 1) the chain's last leaf waits for.\n"
+        f"# round {int(rnd[1:])}, shipped build (sources sha1 {sha}) -- RFLU_ENGINE_TRACE=72:24 python scripts/time_env.py 16384 3 (the accounting instantiation of the kernel):\n"
+        "# the 448 workgroups' time by kind of unit (100 MHz clock, summed over the workgroups); the scheduler's scan phase by phase, microseconds per call; for the leaves\n"
+        "# 72..95 (block columns 9-11) when LEAF(g) was first claimed on the column block of its first columns and -- behind `||` -- on the NEXT block column's first column block\n"
+        "# (the catch-up behind BIG(b - 1) the chain's last leaf waits for); and behind every block column's last leaf what stands between it and BIG(b) being complete on the\n"
+        "# column block the chain needs next: the block column's own deferred interchanges, the 512-row block solve (stage 0), the tiles.\n"
         + "".join(l for l in open(os.path.join(G, rnd, "engine_trace.txt")) if "amdgpu.ids" not in l))
 
 # ---- size table

@@ -2,7 +2,7 @@
 # round 6: everything the documents quote, from ONE box: size table, default bench line, microbenches, rocprofv3 summaries, the engine's
 # counters (replayed alone), the chain leaf by leaf, the engine's workgroup-time table.
 # usage (on the GPU box): bash scripts/r06_final.sh <tag>      then, here: python scripts/install_profiles.py <tag>
-TAG=${1:-r06b}
+TAG=${1:-r06c}
 cd "$(dirname "$0")/.."
 O=gpurun_out/r06; mkdir -p $O
 rm -f $O/bench_n*.json
@@ -28,12 +28,17 @@ python scripts/getrs_check.py > $O/getrs_block.txt 2>&1
 python scripts/time_env.py 16384 4 "" "RFLU_ENGINE=0" "RFLU_ENGINE_AHEAD=2" "RFLU_ENGINE_RETIRE=0" "RFLU_ENGINE_RETIRE=4096" > $O/engine_time.txt 2>&1
 python scripts/time_env.py 16384 4 f32 "" "RFLU_ENGINE=0" >> $O/engine_time.txt 2>&1
 python scripts/time_env.py 16384 4 f64 0 "" "RFLU_ENGINE=1" >> $O/engine_time.txt 2>&1
-python scripts/time_env.py 12288 4 "" "RFLU_ENGINE=1" >> $O/engine_time.txt 2>&1
-python scripts/time_env.py 8192 4 "" "RFLU_ENGINE=1" >> $O/engine_time.txt 2>&1
+python scripts/time_env.py 12288 4 "" "RFLU_ENGINE=0,BS=256" "RFLU_ENGINE=0" >> $O/engine_time.txt 2>&1
+python scripts/time_env.py 12288 4 f32 "" "RFLU_ENGINE=0,BS=256" >> $O/engine_time.txt 2>&1
+python scripts/time_env.py 11264 4 "" "RFLU_ENGINE=1,BS=512" >> $O/engine_time.txt 2>&1
+python scripts/time_env.py 8192 4 "" "RFLU_ENGINE=1,BS=512" >> $O/engine_time.txt 2>&1
 python scripts/tall_panel.py > $O/tall_panel.txt 2>&1
-python scripts/time_env.py 16384 3 "RFLU_ENGINE_TRACE=36:8" > $O/engine_trace.txt 2>&1
+python scripts/time_env.py 16384 3 "RFLU_ENGINE_TRACE=72:24" > $O/engine_trace.txt 2>&1
 python scripts/engine_stress.py 16384 200 > $O/engine_stress.txt 2>&1
 python scripts/engine_stress.py 8192 500 >> $O/engine_stress.txt 2>&1
+RFLU_ENGINE=-1 python scripts/engine_stress.py 12288 300 >> $O/engine_stress.txt 2>&1
+python scripts/engine_stress.py 5000 300 >> $O/engine_stress.txt 2>&1
+python scripts/host_entry_stress.py >> $O/engine_stress.txt 2>&1
 bash scripts/collect_profiles.sh $TAG 16384 > $O/collect_16384.log 2>&1
 bash scripts/collect_profiles.sh ${TAG}_n4096 4096 > $O/collect_4096.log 2>&1
 bash scripts/pmc_engine.sh $TAG 16384 > $O/pmc_engine.log 2>&1

@@ -427,8 +427,8 @@ def main():
                 roof["note_in_schedule"] = ("ONE launch: the engine is resident on 224 of 256 CUs for the whole factorization.  flops = the "
                                             "Schur updates it performs (sum of 2 M N K over its operations), duration = its residency (HIP "
                                             "event pair on its stream), i.e. waiting for the chain of leaves included -- RFLU_ENGINE_TRACE=1 "
-                                            "splits the workgroups' time (profiles/: *_engine_workgroup_time.txt; DESIGN.md section 3: tiles 57 + 7 %, "
-                                            "strips and solves 5 %, between units 30 %); the tile kernel by itself is frac_profiled")
+                                            "splits the workgroups' time (profiles/: *_engine_workgroup_time.txt; DESIGN.md section 3: tiles 59 + 8 %, "
+                                            "strips and solves 5 %, between units 28 %); the tile kernel by itself is frac_profiled")
                 # HBM traffic of the resident kernel: rocprofv3 --pmc runs one kernel at a time, which a kernel that waits for the chain's
                 # kernels cannot survive -- the counters are those of the engine REPLAYED ALONE on a factored image (RFLU_ENGINE_REPLAY=1:
                 # the same operations on the same addresses with every leaf counted as done, scripts/pmc_engine.sh), committed under

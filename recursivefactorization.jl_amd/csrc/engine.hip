@@ -591,6 +591,7 @@ __device__ __attribute__((noinline)) void eng_scan(unsigned long long kernarg)
         }
         // ---- main units: one lane per column block -----------------------------------------------------------------
         int best = INT_MAX;
+        int best2 = INT_MAX, best3 = INT_MAX;   // the runners-up of the chunk the best was found in: tried before a new sweep when the ticket comes back empty
         int first_live = INT_MAX;
         for (int base = cb_lo & ~63; base < a.g.ncb; base += 64) {
             const int cb = base + lane;
@@ -623,7 +624,17 @@ __device__ __attribute__((noinline)) void eng_scan(unsigned long long kernarg)
             int mk = key;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
-            best = min(best, mk);
+            if (mk < best) {
+                best = mk;
+                // (keys are distinct: they carry the column block)
+                int k2 = key > best ? key : INT_MAX;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) k2 = min(k2, __shfl_xor(k2, o));
+                int k3 = key > k2 ? key : INT_MAX;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) k3 = min(k3, __shfl_xor(k3, o));
+                best2 = k2; best3 = k3;
+            }
             if (a.policy == 0 && a.host_lag <= 0 && best != INT_MAX) break;   // leftmost first: nothing further right can beat it
         }
         if (first_live != INT_MAX) cb_lo = first_live;
@@ -632,11 +643,18 @@ __device__ __attribute__((noinline)) void eng_scan(unsigned long long kernarg)
             // fetch-and-add, not compare-and-swap: with a few hundred workgroups arriving together a CAS hands out ONE unit per
             // round trip (the losers rescan: 384 tiles took 0.6 ms to hand out).  Whatever (sequence, unit) the add returns is
             // this workgroup's if the unit exists; a count past the end is nobody's (the next sequence starts from zero again).
-            const int cb = best & 1023;
-            unsigned long long w = 0;
-            if (lane == 0) w = eng_add(&st->cb[cb].claim, 1ull);
-            w = __shfl(w, 0);
-            accept(cb, w);
+            // When a stage of a few units is published (16 block-row solve units, say) every workgroup that comes free in those microseconds
+            // picks it, most tickets come back empty, and each loser used to sweep again: the next-best units of the same sweep are tried first
+            // (their eligibility is as old as the best one's was; whatever the add returns is validated as before).
+            int cand = best;
+            for (int tries = 0; tries < 3 && cand != INT_MAX && kind == ENG_NONE; ++tries) {
+                const int cb = cand & 1023;
+                unsigned long long w = 0;
+                if (lane == 0) w = eng_add(&st->cb[cb].claim, 1ull);
+                w = __shfl(w, 0);
+                accept(cb, w);
+                cand = tries == 0 ? best2 : best3;
+            }
             ENG_PH(3);
             continue;   // (past the end: look again)
         }

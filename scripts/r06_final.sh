@@ -2,7 +2,7 @@
 # round 6: everything the documents quote, from ONE box: size table, default bench line, microbenches, rocprofv3 summaries, the engine's
 # counters (replayed alone), the chain leaf by leaf, the engine's workgroup-time table.
 # usage (on the GPU box): bash scripts/r06_final.sh <tag>      then, here: python scripts/install_profiles.py <tag>
-TAG=${1:-r06c}
+TAG=${1:-r06d}
 cd "$(dirname "$0")/.."
 O=gpurun_out/r06; mkdir -p $O
 rm -f $O/bench_n*.json

@@ -101,7 +101,8 @@ int rflu_debug_engine_acct(rflu_handle_t handle, long long* out8);
  *                  panel of at most 8192 rows (Float32: 16384) on, for widths 128..512: leaf by leaf, right-looking, with only
  *                  the next leaf's 64 columns on the critical path;
  *            = 0 = library default, measured on MI355X: pure recursion below 1024 columns, then block columns of
- *                  256 (<= 12288 columns), 512 (<= 16384), 1024 (<= 24576), 2048 above. */
+ *                  256 (<= 11264 columns), 512 (<= 16384: pivoted, not fat and at most 16384 rows these go through the persistent
+ *                  update engine, RFLU_PATH_HIP_ENGINE), 1024 (<= 24576), 2048 above. */
 int rflu_getrf_f64(rflu_handle_t handle, int64_t m, int64_t n, double* A_host, int64_t lda, int64_t* ipiv_host,
                    int pivot, int64_t blocksize, int64_t* info);
 int rflu_getrf_f32(rflu_handle_t handle, int64_t m, int64_t n, float* A_host, int64_t lda, int64_t* ipiv_host,
